@@ -1,0 +1,182 @@
+"""Pins the NumPy oracle: literal loops, TF SAME-padding adjoint identity, finite differences,
+known answers, and the independent PyTorch-autograd formulation."""
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth
+from oracle import defensegan_oracle as O
+
+
+def small_params(arch="mnist", net_dim=4, latent=8, seed=3, use_bn=False, gain=2.0):
+    return synth.make_weights(arch, seed=seed, gain=gain, bias_range=0.1, use_bn=use_bn,
+                              latent_dim=latent, net_dim=net_dim, bn_jitter=0.2 if use_bn else 0.0)
+
+
+def test_mac_counts_match_survey():
+    assert archs.fwd_macs_per_row(archs.make_arch("mnist")) == 16_572_992
+    assert archs.fwd_macs_per_row(archs.make_arch("celeba")) == 50_226_880
+    # valid taps per dimension
+    assert archs.valid_taps_1d(4, 8) == 17 and archs.valid_taps_1d(4, 7) == 15
+    assert archs.valid_taps_1d(7, 14) == 32 and archs.valid_taps_1d(14, 28) == 67
+    assert archs.valid_taps_1d(8, 16) == 37 and archs.valid_taps_1d(16, 32) == 77
+    assert archs.valid_taps_1d(32, 64) == 157
+    assert abs(archs.flop_per_image(archs.make_arch("mnist"), 10, 200) - 1.32252e11) < 1e7
+
+
+def test_deconv_index_map_1d():
+    # i = 2*o + k - 1: a delta at o=1 with a kernel of distinct values lands at i = 1..5
+    x = np.zeros((1, 4, 4, 1)); x[0, 1, 1, 0] = 1.0
+    F = np.zeros((5, 5, 1, 1)); F[:, :, 0, 0] = np.arange(25).reshape(5, 5) + 1
+    y = O.deconv2d(x, F, None)
+    assert y.shape == (1, 8, 8, 1)
+    for kh in range(5):
+        for kw in range(5):
+            assert y[0, 2 + kh - 1, 2 + kw - 1, 0] == F[kh, kw, 0, 0]
+    assert y.sum() == F.sum()
+    # border clipping: delta at o=0 loses k=0 (i=-1)
+    x = np.zeros((1, 4, 4, 1)); x[0, 0, 0, 0] = 1.0
+    y = O.deconv2d(x, F, None)
+    assert y[0, 0, 0, 0] == F[1, 1, 0, 0] and y.sum() == F[1:, 1:, 0, 0].sum()
+
+
+@pytest.mark.parametrize("h,cin,cout,hout", [(4, 3, 2, None), (4, 3, 2, 7), (7, 2, 3, None), (3, 1, 1, None)])
+def test_deconv_vs_literal(h, cin, cout, hout):
+    rs = np.random.RandomState(0)
+    x = rs.randn(2, h, h, cin); F = rs.randn(5, 5, cout, cin); b = rs.randn(cout)
+    y = O.deconv2d(x, F, b, hout)
+    yl = O.deconv2d_literal(x, F, b, hout)
+    np.testing.assert_allclose(y, yl, rtol=0, atol=1e-12)
+    if hout is not None:   # crop-aware == crop of the full map
+        np.testing.assert_allclose(y, O.deconv2d(x, F, b)[:, :hout, :hout], atol=1e-12)
+
+
+@pytest.mark.parametrize("h,hout", [(4, 8), (4, 7), (7, 14)])
+def test_deconv_is_adjoint_of_tf_same_conv(h, hout):
+    """conv2d_transpose is DEFINED as the input-gradient of the SAME stride-2 conv whose padding
+    rule is pad_before = pad_total // 2 = 1.  <conv(y), x> == <y, deconv(x)>."""
+    rs = np.random.RandomState(1)
+    cin, cout = 3, 2
+    x = rs.randn(2, h, h, cin); F = rs.randn(5, 5, cout, cin)
+    y = rs.randn(2, hout, hout, cout)
+    lhs = (O.conv2d_same_s2_literal(y, F, h) * x).sum()
+    rhs = (y * O.deconv2d(x, F, None, hout)).sum()
+    assert abs(lhs - rhs) < 1e-9 * max(1, abs(lhs))
+    np.testing.assert_allclose(O.deconv2d_backward_input(y, F, h), O.conv2d_same_s2_literal(y, F, h), atol=1e-12)
+
+
+def test_nhwc_reshape_of_linear_output():
+    p = small_params()
+    z = np.random.RandomState(0).randn(3, 8)
+    _, cache = O.generator_forward(p, z.astype(np.float64), "mnist")
+    h1 = cache["acts"][0]
+    a = np.maximum(z @ p["Generator.Input.W"].astype(np.float64) + p["Generator.Input.b"], 0)
+    C = h1.shape[3]
+    for oh in range(4):
+        for ow in range(4):
+            np.testing.assert_allclose(h1[:, oh, ow, :], a[:, (oh * 4 + ow) * C:(oh * 4 + ow + 1) * C], atol=1e-14)
+
+
+@pytest.mark.parametrize("arch", ["mnist", "celeba"])
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_gradient_finite_difference(arch, use_bn):
+    p = small_params(arch, use_bn=use_bn)
+    rs = np.random.RandomState(5)
+    N = 5
+    z = rs.randn(N, 8) * 0.3
+    a = archs.make_arch(arch, 8, 4)
+    x = rs.rand(N, *a.image_dim)
+    P = a.pixels
+
+    def total(zz):
+        y, _ = O.generator_forward(p, zz, arch, use_bn)
+        return ((y - x) ** 2).reshape(N, -1).mean(axis=1).sum()
+
+    y, cache = O.generator_forward(p, z, arch, use_bn)
+    g = O.generator_backward(p, cache, 2.0 / P * (y - x), arch, use_bn)
+    eps = 1e-6
+    for (r, d) in [(0, 0), (1, 3), (4, 7), (2, 5)]:
+        zp = z.copy(); zp[r, d] += eps
+        zm = z.copy(); zm[r, d] -= eps
+        fd = (total(zp) - total(zm)) / (2 * eps)
+        assert abs(fd - g[r, d]) < 1e-6 * max(1.0, abs(fd)), (r, d, fd, g[r, d])
+
+
+@pytest.mark.parametrize("arch", ["mnist", "celeba"])
+@pytest.mark.parametrize("use_bn", [False, True])
+def test_numpy_vs_torch_autograd_fp64(arch, use_bn):
+    import torch
+    from oracle import torch_ref as T
+    p = small_params(arch, use_bn=use_bn)
+    a = archs.make_arch(arch, 8, 4)
+    rs = np.random.RandomState(2)
+    B, R, L = 3, 2, 4
+    z0 = rs.randn(B * R, 8) * 0.3
+    x = rs.rand(B, *a.image_dim) * (a.in_hi - a.in_lo) + a.in_lo
+    o = O.reconstruct(p, x, z0, R, L, lr=1.0, arch=arch, use_bn=use_bn, dtype=np.float64)
+    t = T.reconstruct(p, x, z0, R, L, lr=1.0, arch=arch, use_bn=use_bn, dtype=torch.float64)
+    np.testing.assert_allclose(o["loss"], t["loss"], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(o["z"], t["z"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(o["rec"], t["rec"], rtol=1e-9, atol=1e-12)
+    assert (o["idx"] == t["idx"]).all()
+
+
+def test_schedule_momentum_and_selection():
+    """L forwards / L-1 updates; L=0 and L=1 return G(z0); momentum recurrence; first-min tie-break;
+    constant lr."""
+    p = small_params()
+    a = archs.make_arch("mnist", 8, 4)
+    rs = np.random.RandomState(4)
+    B, R = 2, 3
+    z0 = rs.randn(B * R, 8) * 0.3
+    z0[1] = z0[0]          # identical restarts for image 0 -> identical losses -> idx must be the first
+    z0[2] = z0[0]
+    x = rs.rand(B, 28, 28, 1)
+    o0 = O.reconstruct(p, x, z0, R, 0, dtype=np.float64)
+    o1 = O.reconstruct(p, x, z0, R, 1, dtype=np.float64)
+    y0, _ = O.generator_forward(p, z0, "mnist")
+    np.testing.assert_array_equal(o0["y"], y0)
+    np.testing.assert_array_equal(o1["y"], y0)
+    np.testing.assert_array_equal(o1["z"], z0)
+    assert o0["idx"][0] == 0
+    # two manual steps of non-Nesterov momentum with constant lr
+    lr, mom, P = 10.0, 0.7, 784
+    z = z0.copy(); m = np.zeros_like(z)
+    xt = np.repeat(x, R, axis=0)
+    for _ in range(2):
+        y, c = O.generator_forward(p, z, "mnist")
+        g = O.generator_backward(p, c, 2.0 / P * (y - xt), "mnist")
+        m = mom * m + g
+        z = z - lr * m
+    o3 = O.reconstruct(p, x, z0, R, 3, lr=lr, momentum=mom, dtype=np.float64)
+    np.testing.assert_allclose(o3["z"], z, rtol=1e-12, atol=1e-14)
+    y, _ = O.generator_forward(p, z, "mnist")
+    np.testing.assert_allclose(o3["y"], y, rtol=1e-12, atol=1e-14)
+    # rec gathers row b*R + idx
+    for b in range(B):
+        np.testing.assert_array_equal(o3["rec"][b], o3["y"][b * R + o3["idx"][b]])
+        assert o3["idx"][b] == np.argmin(o3["loss"][b * R:(b + 1) * R])
+
+
+def test_bn_uses_full_map_statistics_before_crop():
+    p = small_params("mnist", use_bn=True)
+    z = np.random.RandomState(0).randn(6, 8) * 0.5
+    _, c = O.generator_forward(p, z, "mnist", True)
+    xhat, _ = c["bn_Generator.2"]
+    assert xhat.shape[1:3] == (8, 8)
+    np.testing.assert_allclose(xhat.mean(axis=(0, 1, 2)), 0, atol=1e-12)
+
+
+def test_contractive_regime_converges_fp32_vs_fp64():
+    """gain 2.0, clean in-range targets: the loop converges and fp32 tracks fp64."""
+    p = synth.make_weights("mnist", seed=1234, gain=2.0, latent_dim=16, net_dim=8)
+    rs = np.random.RandomState(0)
+    B, R, L = 2, 2, 60
+    zt = rs.randn(B, 16).astype(np.float32) * 0.25
+    x, _ = O.generator_forward(p, zt, "mnist")
+    z0 = rs.randn(B * R, 16).astype(np.float32) * 0.25
+    o32 = O.reconstruct(p, x, z0, R, L, dtype=np.float32)
+    o64 = O.reconstruct(p, x, z0, R, L, dtype=np.float64)
+    l0 = O.reconstruct(p, x, z0, R, 1, dtype=np.float64)["loss"]
+    assert (o64["loss"] < 0.2 * l0).all()
+    np.testing.assert_allclose(o32["loss"], o64["loss"], rtol=2e-3, atol=1e-7)
+    assert (o32["idx"] == o64["idx"]).all()
