@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the Defense-GAN latent-projection hot path on MI355X.
+
+metric : projected images/sec at L=200, R=10 (MNIST 28x28)      (BASELINE.json)
+step   : one pass of the hot path (dg_reconstruct) over one batch of B synthetic images per GPU,
+         inputs already resident in HBM; weak scaling (every rank projects its own batch).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from defensegan_amd import archs, synth
+from defensegan_amd.gan import dataset_gan_dict
+
+PEAK_FP32_TFLOPS = 157.3        # MI355X fp32 MFMA == fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (arch, weight seed, gain, B, R, L)
+    "mnist": ("mnist", 1234, 2.0, 256, 10, 200),       # BASELINE configs[1]
+    "fmnist": ("f-mnist", 4321, 2.0, 256, 10, 200),    # configs[2]
+    "celeba": ("celeba", 1234, 2.0, 128, 10, 200),     # configs[3]
+}
+
+
+def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
+    """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed
+    here) on this box's host cores, bounded sample, scaled to images/s at the full L."""
+    from oracle import torch_ref as T          # checker / baseline only -- never on the product path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = T.TorchGenerator(params, arch)
+    nimg = min(16, len(x_np))
+    a = archs.make_arch(arch)
+    z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
+    Ls = 3
+    t0 = time.perf_counter()
+    T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)       # warm-up + probe
+    probe = time.perf_counter() - t0
+    per_pass = probe / (2 * Ls - 1)
+    Ls = int(max(3, min(L, (budget_s / max(per_pass, 1e-6) + 1) // 2)))
+    t0 = time.perf_counter()
+    T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
+    dt = time.perf_counter() - t0
+    t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # work is linear in (2L-1) passes
+    return {"value": nimg / t_full, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images x R=%d x L=%d (torch-CPU autograd restatement, %d threads, %.1f s), "
+                      "scaled by (2L-1) to L=%d" % (nimg, R, Ls, cores, dt, L)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mnist", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--rec_rr", type=int, default=None)
+    ap.add_argument("--rec_iters", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stride", type=int, default=10,
+                    help="bracket every kernel of each k-th GD iteration with hipEvents (0 = off)")
+    ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    arch, wseed, gain, B, R, L = WORKLOADS[args.workload]
+    B = args.batch or B
+    R = args.rec_rr or R
+    L = args.rec_iters or L
+    a = archs.make_arch(arch)
+    params = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=0.0)
+    gan = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim},
+                                 test_mode=True, rec_rr=R, rec_iters=L, rec_lr=10.0, device=local_rank)
+    assert gan.set_weights(params) == []
+    for kv in args.opt:
+        k, v = kv.split("=", 1)
+        gan.set_option(k, v)
+
+    # synthetic inputs, resident in HBM: x = clip(G(z_true) + 0.3*sign(noise)) (FGSM-eps-0.3-like), per rank
+    zt = gan.init_latents(B, seed=1000 + rank)
+    x = gan.generate(zt)
+    noise = torch.randn(x.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
+    x = torch.clamp(x + 0.3 * torch.sign(noise), a.in_lo, a.in_hi).contiguous()
+
+    def step(i):
+        # a new batch of images every step: global row index advances, so z0 differs
+        first_row = ((i * world) + rank) * B * R
+        return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    gan.profile_reset()
+    gan.profile_enable(args.profile_stride)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    if distributed:
+        # the path's one exchange: per-image (selected restart, best loss) gathered over RCCL/xGMI
+        best = out["loss"].view(B, R).min(dim=1).values
+        msg = torch.stack([out["idx"].float(), best], dim=1).contiguous()
+        gathered = [torch.empty_like(msg) for _ in range(world)]
+        dist.all_gather(gathered, msg)
+    barrier()
+    dt = time.perf_counter() - t0
+    gan.profile_enable(0)
+    if distributed:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = gan.profile_read()
+    if rank == 0:
+        images = world * B * args.steps
+        value = images / dt
+        flop_img = archs.flop_per_image(a, R, max(L, 1))
+        path_tflops = value * flop_img / 1e12 / world           # per GPU
+        kernels = []
+        for p in prof:
+            if p["launches"] == 0:
+                continue
+            avg_ms = p["ms"] / p["launches"]
+            tf = (p["flops"] / p["launches"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            kernels.append({"name": p["name"], "launches_sampled": p["launches"], "avg_us": round(avg_ms * 1e3, 2),
+                            "tflops": round(tf, 2)})
+        dom = max(kernels, key=lambda k: k["avg_us"]) if kernels else None
+        roofline = {
+            "bound": "mfma",
+            "kernel": dom["name"] if dom else None,
+            "achieved": dom["tflops"] if dom else round(path_tflops, 2),
+            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": round((dom["tflops"] if dom else path_tflops) / PEAK_FP32_TFLOPS, 4),
+            "traffic": None,
+            "path_achieved": round(path_tflops, 2),
+            "path_frac": round(path_tflops / PEAK_FP32_TFLOPS, 4),
+        }
+        loss = out["loss"].view(B, R).min(dim=1).values
+        res = {
+            "metric": "projected images/sec at L=%d,R=%d (%s)" % (L, R, "MNIST 28x28" if a.arch_id == 0 else "CelebA 64x64"),
+            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s L=%d R=%d batch=%d fp32 (BASELINE configs[%d]); synthetic tflib-init weights "
+                                   "gain %.1f, x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B,
+                                                                               {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload], gain),
+                       "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0, "parallelism": "shard%d" % world},
+            "roofline": roofline,
+            "kernels": kernels,
+            "mean_best_loss": round(float(loss.mean().item()), 6),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(arch, params, x.cpu().numpy(), R, L)
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    gan.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,72 @@
+"""ctypes binding of include/defensegan_hip.h (the C-ABI drop-in boundary).
+
+The product path has NO fallback: if the HIP library is missing or does not load, importing a
+compute entry point raises.  PyTorch-ROCm is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdefensegan_hip.so")
+
+DG_OK = 0
+ABI_VERSION = 1
+
+# every symbol include/defensegan_hip.h declares: (name, restype, argtypes)
+_vp, _i, _i64, _u64, _f, _cp = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_char_p
+SYMBOLS = [
+    ("dg_version", _i, []),
+    ("dg_last_error", _cp, []),
+    ("dg_device_count", _i, []),
+    ("dg_device_info", _i, [_i, _cp, _i, C.POINTER(_i), C.POINTER(_i64)]),
+    ("dg_create", _i, [_i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    ("dg_destroy", _i, [_vp]),
+    ("dg_set_weights", _i, [_vp, _cp, _vp, C.POINTER(_i64), _i, _i]),
+    ("dg_weights_complete", _i, [_vp]),
+    ("dg_reconstruct", _i, [_vp, _vp, _vp, _u64, _i64, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    ("dg_generate", _i, [_vp, _vp, _i, _vp, _vp]),
+    ("dg_loss_grad", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("dg_init_latents", _i, [_vp, _vp, _i64, _u64, _i64, _f, _vp]),
+    ("dg_profile_enable", _i, [_vp, _i]),
+    ("dg_profile_count", _i, [_vp]),
+    ("dg_profile_read", _i, [_vp, _i, _cp, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dg_profile_reset", _i, [_vp]),
+    ("dg_debug_read", _i64, [_vp, _cp, _vp, _i64]),
+    ("dg_set_option", _i, [_vp, _cp, _cp]),
+]
+
+_lib: Optional[C.CDLL] = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Loads the in-tree HIP library; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`python defensegan_amd/build.py`); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.dg_version()
+    if v != ABI_VERSION:
+        raise NativeError("ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != DG_OK:
+        msg = load().dg_last_error()
+        raise NativeError("defensegan_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,70 @@
+"""Builds the HIP shared library in-tree (defensegan_amd/lib/libdefensegan_hip.so) for gfx950.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libdefensegan_hip.so")
+SOURCES = ["dg_engine.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_tail.hip", "dg_small.hip"]
+HEADERS = ["dg_kernels.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".", "_") + ".o")
+        objs.append(obj)
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+               os.path.join(CSRC, src), "-o", obj, "-I", CSRC]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on " + src)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,649 @@
+// Host side of the C ABI (include/defensegan_hip.h): handle, weights, workspace, launch sequence.
+//
+// The launch sequence restates DefenseGANBase.reconstruct (/root/reference/models/gan.py:333-449) as a
+// fixed per-iteration kernel chain on one HIP stream:
+//   F1 Linear+ReLU -> Fk Deconv+ReLU ... -> tail (last Deconv + sigmoid/tanh + loss [+ its backward])
+//   -> Bk Deconv backward (+ReluGrad, in place over the activation) ... -> B1 Linear backward (split-K)
+//   -> momentum update.
+// The L-th iteration runs the forward half only (the reference discards the L-th update), then the
+// per-image first-argmin over restarts gathers the output.  No host round trip inside the loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/defensegan_hip.h"
+#include "dg_kernels.h"
+#include "dg_plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(DG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+struct DeconvSpec {
+    const char* name;   // reference layer name
+    int cin, cout, h_in, e_used;
+    int act;            // 0 relu, 1 none, 2 final (sigmoid / tanh in the tail)
+};
+
+struct GemmOp {
+    std::string name;
+    dg::LayerPlan plan;
+    dg::PosEntry* d_pos = nullptr;
+    dg::TapEntry* d_taps = nullptr;
+    int tile = 0;
+    int mode = 0;
+    const float* W = nullptr;
+    const float* bias = nullptr;
+};
+
+struct ProfEntry {
+    std::string name;
+    int64_t launches = 0;
+    double ms = 0.0;
+    double flops = 0.0;   // algorithmic FLOP of the measured launches
+};
+struct ProfPending {
+    int entry;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct dg_handle {
+    int arch = 0, latent = 0, net_dim = 0, use_bn = 0, device = 0;
+    int img_h = 0, img_c = 0, P = 0;
+    int lin_out = 0;
+    std::vector<DeconvSpec> dec;
+
+    // weights (device, engine-owned)
+    float* lin_w = nullptr;    // [latent][lin_out]   reference layout; K-contiguous operand of the backward
+    float* lin_wt = nullptr;   // [lin_out][latent]   K-contiguous operand of the forward
+    float* lin_b = nullptr;
+    std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
+    std::map<std::string, bool> have;
+
+    // ops
+    GemmOp F1, B1;
+    std::vector<GemmOp> Fd, Bd;   // per non-final deconv
+    int nsplit = 8;
+    std::map<std::string, int> tile_override;
+
+    // workspace
+    int64_t cap_rows = 0;
+    float *z = nullptr, *m = nullptr, *part = nullptr, *loss = nullptr, *y = nullptr;
+    float* xzero = nullptr;        // [P] zeros: stand-in target for dg_generate
+    std::vector<float*> act;       // act[0] = h1 [N, lin_out]; act[d+1] = output of deconv d (non-final)
+    std::vector<int64_t> act_row;  // floats per latent row
+
+    // profiling
+    int prof_stride = 0;
+    std::vector<ProfEntry> prof;
+    std::vector<ProfPending> pending;
+    std::map<std::string, int> prof_index;
+};
+
+namespace {
+
+int prof_slot(dg_handle* h, const std::string& name) {
+    auto it = h->prof_index.find(name);
+    if (it != h->prof_index.end()) return it->second;
+    h->prof.push_back(ProfEntry{name, 0, 0.0, 0.0});
+    h->prof_index[name] = (int)h->prof.size() - 1;
+    return (int)h->prof.size() - 1;
+}
+
+struct ProfScope {   // brackets one launch with events when sampling is on for this iteration
+    dg_handle* h;
+    hipStream_t s;
+    bool on;
+    int entry = -1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double flops;
+    ProfScope(dg_handle* h_, hipStream_t s_, bool on_, const std::string& name, double flops_)
+        : h(h_), s(s_), on(on_), flops(flops_) {
+        if (!on) return;
+        entry = prof_slot(h, name);
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(e0, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(e1, s);
+        h->pending.push_back(ProfPending{entry, e0, e1});
+        h->prof[entry].flops += flops;
+    }
+};
+
+void prof_collect(dg_handle* h) {
+    for (auto& p : h->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            h->prof[p.entry].ms += ms;
+            h->prof[p.entry].launches += 1;
+        }
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    h->pending.clear();
+}
+
+int upload_plan(GemmOp& op) {
+    if (op.d_pos) { (void)hipFree(op.d_pos); op.d_pos = nullptr; }
+    if (op.d_taps) { (void)hipFree(op.d_taps); op.d_taps = nullptr; }
+    HIP_TRY(hipMalloc(&op.d_pos, op.plan.pos.size() * sizeof(dg::PosEntry)));
+    HIP_TRY(hipMalloc(&op.d_taps, op.plan.taps.size() * sizeof(dg::TapEntry)));
+    HIP_TRY(hipMemcpy(op.d_pos, op.plan.pos.data(), op.plan.pos.size() * sizeof(dg::PosEntry), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(op.d_taps, op.plan.taps.data(), op.plan.taps.size() * sizeof(dg::TapEntry), hipMemcpyHostToDevice));
+    return DG_OK;
+}
+
+int default_tile(const std::string& name, int ncols) {
+    // tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very
+    // different K (1..9 or 4..25 taps), so 64-row M tiles keep the dispatch balanced at B*R ~ 2560.
+    if (ncols % 128 != 0) return 2;   // 64 output columns: 128x64
+    if (name == "F1") return 0;       // Linear forward: uniform K = latent, 128x128
+    return 1;                         // 64x128
+}
+
+int build_plans(dg_handle* h) {
+    auto tile_for = [&](const std::string& name, int ncols) {
+        auto it = h->tile_override.find(name);
+        int t = it != h->tile_override.end() ? it->second : default_tile(name, ncols);
+        if (ncols % dg::gemm_tile_bn(t) != 0) t = (t & 1) ? 3 : 2;   // fall back to 64 columns
+        return t;
+    };
+    {
+        GemmOp& op = h->F1;
+        op.name = "F1";
+        op.tile = tile_for(op.name, h->lin_out);
+        op.plan = dg::plan_linear_fwd(h->latent, h->lin_out, dg::gemm_tile_bn(op.tile));
+        op.mode = h->use_bn ? dg::EPI_BIAS : dg::EPI_BIAS_RELU;
+        int rc = upload_plan(op);
+        if (rc) return rc;
+    }
+    {
+        GemmOp& op = h->B1;
+        op.name = "B1";
+        op.tile = tile_for(op.name, h->latent);
+        op.plan = dg::plan_linear_bwd(h->latent, h->lin_out, h->nsplit, dg::gemm_tile_bn(op.tile));
+        op.mode = dg::EPI_STORE;
+        int rc = upload_plan(op);
+        if (rc) return rc;
+    }
+    const int nd = (int)h->dec.size();
+    for (auto* v : {&h->Fd, &h->Bd})
+        for (auto& o : *v) {
+            if (o.d_pos) (void)hipFree(o.d_pos);
+            if (o.d_taps) (void)hipFree(o.d_taps);
+        }
+    h->Fd.assign(nd - 1, GemmOp());
+    h->Bd.assign(nd - 1, GemmOp());
+    for (int d = 0; d + 1 < nd; ++d) {
+        const DeconvSpec& s = h->dec[d];
+        const int e = s.e_used;          // positions computed and stored (row pitch = e)
+        const int in_pitch = d == 0 ? 4 : h->dec[d - 1].e_used;
+        {
+            GemmOp& op = h->Fd[d];
+            op.name = std::string("F") + s.name[10];     // "Generator.N" -> "FN"
+            op.tile = tile_for(op.name, s.cout);
+            op.plan = dg::plan_deconv_fwd(s.h_in, in_pitch, e, e, s.cin, s.cout, dg::gemm_tile_bn(op.tile));
+            op.mode = s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS;
+            int rc = upload_plan(op);
+            if (rc) return rc;
+        }
+        {
+            GemmOp& op = h->Bd[d];
+            op.name = std::string("B") + s.name[10];
+            op.tile = tile_for(op.name, s.cin);
+            op.plan = dg::plan_deconv_bwd(s.h_in, in_pitch, e, e, s.cin, s.cout, dg::gemm_tile_bn(op.tile));
+            op.mode = dg::EPI_MASK;      // every backward output lands on a ReLU activation (h1, h2, h3)
+            int rc = upload_plan(op);
+            if (rc) return rc;
+        }
+    }
+    return DG_OK;
+}
+
+void free_workspace(dg_handle* h) {
+    auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y);
+    for (auto& a : h->act) fr(a);
+    h->cap_rows = 0;
+}
+
+int ensure_workspace(dg_handle* h, int64_t rows) {
+    if (rows <= h->cap_rows) return DG_OK;
+    free_workspace(h);
+    const int64_t cap = rows;
+    HIP_TRY(hipMalloc(&h->z, cap * h->latent * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->m, cap * h->latent * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->part, cap * h->nsplit * h->latent * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->loss, cap * sizeof(float)));
+    HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
+    const int nd = (int)h->dec.size();
+    h->act.assign(nd, nullptr);
+    h->act_row.assign(nd, 0);
+    h->act_row[0] = h->lin_out;
+    for (int d = 0; d + 1 < nd; ++d) h->act_row[d + 1] = (int64_t)h->dec[d].e_used * h->dec[d].e_used * h->dec[d].cout;
+    for (int d = 0; d < nd; ++d) HIP_TRY(hipMalloc(&h->act[d], cap * h->act_row[d] * sizeof(float)));
+    h->cap_rows = cap;
+    return DG_OK;
+}
+
+void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    dg::GemmArgs a;
+    a.A = A;
+    a.W = op.W;
+    a.Out = Out;
+    a.bias = op.bias;
+    a.pos = op.d_pos;
+    a.taps = op.d_taps;
+    a.a_rowstride = op.plan.a_rowstride;
+    a.out_rowstride = op.plan.out_rowstride;
+    a.w_rowstride = op.plan.w_rowstride;
+    a.kch = op.plan.kch;
+    a.n_rows = n_rows;
+    const int bm = dg::gemm_tile_bm(op.tile);
+    a.n_mtiles = (n_rows + bm - 1) / bm;
+    a.mode = op.mode;
+    ProfScope ps(h, s, prof, op.name, 2.0 * (double)op.plan.macs_per_row * n_rows);
+    dg::launch_gemm(op.tile, a, (int)op.plan.pos.size(), s);
+}
+
+// forward chain at the current h->z; fills activations, loss, (y when want_y); when do_backward the tail also
+// leaves the gradient w.r.t. the last GEMM activation in place.
+void run_forward(dg_handle* h, const float* x, int n_rows, int R, bool want_y, bool tail_backward, hipStream_t s,
+                 bool prof) {
+    run_gemm(h, h->F1, h->z, h->act[0], n_rows, s, prof);
+    const int nd = (int)h->dec.size();
+    for (int d = 0; d + 1 < nd; ++d) run_gemm(h, h->Fd[d], h->act[d], h->act[d + 1], n_rows, s, prof);
+    const DeconvSpec& last = h->dec[nd - 1];
+    if (h->arch == DG_ARCH_MNIST28) {
+        dg::MnistTailArgs t;
+        t.h3 = h->act[nd - 1];
+        t.F5 = h->F[nd - 1];
+        t.b5 = h->bias[nd - 1];
+        t.x = x;
+        t.loss = h->loss;
+        t.y = want_y ? h->y : nullptr;
+        t.n_rows = n_rows;
+        t.R = R;
+        t.C = last.cin;
+        t.do_backward = tail_backward ? 1 : 0;
+        const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
+        ProfScope ps(h, s, prof, tail_backward ? "T5fb" : "T5f", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
+        dg::launch_mnist_tail(t, s);
+    }
+}
+
+void run_backward(dg_handle* h, int n_rows, hipStream_t s, bool prof) {
+    const int nd = (int)h->dec.size();
+    for (int d = nd - 2; d >= 0; --d) run_gemm(h, h->Bd[d], h->act[d + 1], h->act[d], n_rows, s, prof);
+    run_gemm(h, h->B1, h->act[0], h->part, n_rows, s, prof);
+}
+
+int check_ready(dg_handle* h) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    if (!dg_weights_complete(h)) return fail(DG_E_STATE, "generator weights are not completely set (dg_set_weights)");
+    return DG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dg_version(void) { return DG_ABI_VERSION; }
+const char* dg_last_error(void) { return g_err.c_str(); }
+
+int dg_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail(DG_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); return DG_E_HIP; }
+    return n;
+}
+
+int dg_device_info(int device, char* name, int name_len, int* cu_count, int64_t* hbm_bytes) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    return DG_OK;
+}
+
+int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_handle** out) {
+    if (!out) return fail(DG_E_INVALID, "out is null");
+    *out = nullptr;
+    if (arch != DG_ARCH_MNIST28 && arch != DG_ARCH_CELEBA64) return fail(DG_E_INVALID, "unknown arch %d", arch);
+    if (latent_dim <= 0 || latent_dim % 64) return fail(DG_E_INVALID, "latent_dim must be a positive multiple of 64 (got %d)", latent_dim);
+    if (net_dim <= 0 || net_dim % 64 || net_dim > 128) return fail(DG_E_INVALID, "net_dim must be 64 or 128 (got %d)", net_dim);
+    if (use_bn) return fail(DG_E_INVALID, "use_bn=True is not built yet in this round");
+    if (arch == DG_ARCH_CELEBA64) return fail(DG_E_INVALID, "celeba64 is not built yet in this round");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(DG_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    dg_handle* h = new dg_handle();
+    h->arch = arch;
+    h->latent = latent_dim;
+    h->net_dim = net_dim;
+    h->use_bn = use_bn;
+    h->device = device;
+    h->lin_out = 4 * 4 * 4 * net_dim;
+    const int nd = net_dim;
+    if (arch == DG_ARCH_MNIST28) {
+        h->img_h = 28; h->img_c = 1;
+        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 7, 0}, {"Generator.3", 2 * nd, nd, 7, 14, 0},
+                  {"Generator.5", nd, 1, 14, 28, 2}};
+    } else {
+        h->img_h = 64; h->img_c = 3;
+        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 8, 0}, {"Generator.3", 2 * nd, nd, 8, 16, 0},
+                  {"Generator.5", nd, nd, 16, 32, 1}, {"Generator.6", nd, 3, 32, 64, 2}};
+    }
+    h->P = h->img_h * h->img_h * h->img_c;
+    const size_t ndec = h->dec.size();
+    h->F.assign(ndec, nullptr);
+    h->Ft.assign(ndec, nullptr);
+    h->bias.assign(ndec, nullptr);
+    hipError_t e = hipSuccess;
+    auto dmalloc = [&](float** p, size_t n) { if (e == hipSuccess) e = hipMalloc(p, n * sizeof(float)); };
+    dmalloc(&h->lin_w, (size_t)h->latent * h->lin_out);
+    dmalloc(&h->lin_wt, (size_t)h->latent * h->lin_out);
+    dmalloc(&h->lin_b, h->lin_out);
+    dmalloc(&h->xzero, h->P);
+    for (size_t d = 0; d < ndec; ++d) {
+        dmalloc(&h->F[d], (size_t)25 * h->dec[d].cout * h->dec[d].cin);
+        dmalloc(&h->Ft[d], (size_t)25 * h->dec[d].cout * h->dec[d].cin);
+        dmalloc(&h->bias[d], h->dec[d].cout);
+    }
+    if (e == hipSuccess) e = hipMemset(h->xzero, 0, (size_t)h->P * sizeof(float));
+    if (e != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(weights): %s", hipGetErrorString(e)); }
+    int rc = build_plans(h);
+    if (rc) { dg_destroy(h); return rc; }
+    h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
+    h->B1.W = h->lin_w;
+    for (size_t d = 0; d + 1 < ndec; ++d) {
+        h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
+        h->Bd[d].W = h->Ft[d];
+    }
+    *out = h;
+    return DG_OK;
+}
+
+int dg_destroy(dg_handle* h) {
+    if (!h) return DG_OK;
+    (void)hipSetDevice(h->device);
+    prof_collect(h);
+    free_workspace(h);
+    auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero);
+    for (auto& p : h->F) fr(p);
+    for (auto& p : h->Ft) fr(p);
+    for (auto& p : h->bias) fr(p);
+    auto frop = [](GemmOp& op) {
+        if (op.d_pos) (void)hipFree(op.d_pos);
+        if (op.d_taps) (void)hipFree(op.d_taps);
+        op.d_pos = nullptr; op.d_taps = nullptr;
+    };
+    frop(h->F1); frop(h->B1);
+    for (auto& o : h->Fd) frop(o);
+    for (auto& o : h->Bd) frop(o);
+    delete h;
+    return DG_OK;
+}
+
+int dg_set_weights(dg_handle* h, const char* name, const float* data, const int64_t* shape, int ndim, int is_device) {
+    if (!h || !name || !data || !shape) return fail(DG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    std::vector<float> host((size_t)n);
+    HIP_TRY(hipMemcpy(host.data(), data, (size_t)n * sizeof(float), is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    const std::string nm(name);
+    auto shape_is = [&](std::initializer_list<int64_t> want) {
+        if ((int)want.size() != ndim) return false;
+        int i = 0;
+        for (int64_t w : want) if (shape[i++] != w) return false;
+        return true;
+    };
+    if (nm == "Generator.Input.W") {
+        if (!shape_is({h->latent, h->lin_out})) return fail(DG_E_INVALID, "%s: expected shape [%d,%d]", name, h->latent, h->lin_out);
+        std::vector<float> t((size_t)n);
+        for (int d = 0; d < h->latent; ++d)
+            for (int f = 0; f < h->lin_out; ++f) t[(size_t)f * h->latent + d] = host[(size_t)d * h->lin_out + f];
+        HIP_TRY(hipMemcpy(h->lin_w, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->lin_wt, t.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        h->have[nm] = true;
+        return DG_OK;
+    }
+    if (nm == "Generator.Input.b") {
+        if (!shape_is({h->lin_out})) return fail(DG_E_INVALID, "%s: expected shape [%d]", name, h->lin_out);
+        HIP_TRY(hipMemcpy(h->lin_b, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        h->have[nm] = true;
+        return DG_OK;
+    }
+    for (size_t d = 0; d < h->dec.size(); ++d) {
+        const DeconvSpec& s = h->dec[d];
+        if (nm == std::string(s.name) + ".Filters") {
+            if (!shape_is({5, 5, s.cout, s.cin})) return fail(DG_E_INVALID, "%s: expected shape [5,5,%d,%d]", name, s.cout, s.cin);
+            std::vector<float> t((size_t)n);
+            for (int k = 0; k < 25; ++k)
+                for (int co = 0; co < s.cout; ++co)
+                    for (int ci = 0; ci < s.cin; ++ci)
+                        t[((size_t)k * s.cin + ci) * s.cout + co] = host[((size_t)k * s.cout + co) * s.cin + ci];
+            HIP_TRY(hipMemcpy(h->F[d], host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(h->Ft[d], t.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            h->have[nm] = true;
+            return DG_OK;
+        }
+        if (nm == std::string(s.name) + ".Biases") {
+            if (!shape_is({s.cout})) return fail(DG_E_INVALID, "%s: expected shape [%d]", name, s.cout);
+            HIP_TRY(hipMemcpy(h->bias[d], host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            h->have[nm] = true;
+            return DG_OK;
+        }
+    }
+    return fail(DG_E_INVALID, "unknown weight name '%s'", name);
+}
+
+int dg_weights_complete(dg_handle* h) {
+    if (!h) return 0;
+    if (!h->have.count("Generator.Input.W") || !h->have.count("Generator.Input.b")) return 0;
+    for (auto& s : h->dec) {
+        if (!h->have.count(std::string(s.name) + ".Filters")) return 0;
+        if (!h->have.count(std::string(s.name) + ".Biases")) return 0;
+    }
+    return 1;
+}
+
+int dg_init_latents(dg_handle* h, float* z, int64_t n_rows, uint64_t seed, int64_t first_row, float std, void* stream) {
+    if (!h || !z || n_rows < 0) return fail(DG_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    if (std <= 0.f) std = std::sqrt(1.0f / (float)h->latent);
+    if (n_rows) dg::launch_init_latents(z, n_rows, h->latent, seed, first_row, std, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return DG_OK;
+}
+
+int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed, int64_t first_row, int B, int R, int L,
+                   float lr, float momentum, float* out_rec, int32_t* out_idx, float* out_loss, float* out_z,
+                   void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!x || !out_rec) return fail(DG_E_INVALID, "x and out_rec must be non-null");
+    if (B < 1 || R < 1 || L < 0) return fail(DG_E_INVALID, "need B >= 1, R >= 1, L >= 0 (got %d, %d, %d)", B, R, L);
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t rows64 = (int64_t)B * R;
+    if (rows64 > (1 << 24)) return fail(DG_E_INVALID, "B*R = %lld is too large for one call", (long long)rows64);
+    const int n_rows = (int)rows64;
+    rc = ensure_workspace(h, n_rows);
+    if (rc) return rc;
+    const size_t zbytes = (size_t)n_rows * h->latent * sizeof(float);
+    if (z0) HIP_TRY(hipMemcpyAsync(h->z, z0, zbytes, hipMemcpyDeviceToDevice, s));
+    else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
+    HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
+    const int steps = L > 1 ? L : 1;
+    for (int k = 0; k < steps; ++k) {
+        const bool last = (k == steps - 1);
+        const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
+        run_forward(h, x, n_rows, R, /*want_y=*/last, /*tail_backward=*/!last, s, prof);
+        if (last) break;
+        run_backward(h, n_rows, s, prof);
+        {
+            ProfScope ps(h, s, prof, "UPD", 0.0);
+            dg::launch_momentum_update(h->z, h->m, h->part, h->nsplit, n_rows, h->latent, lr, momentum, nullptr, s);
+        }
+    }
+    dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
+    if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_z) HIP_TRY(hipMemcpyAsync(out_z, h->z, zbytes, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGetLastError());
+    return DG_OK;
+}
+
+int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!z || !out_y || N < 1) return fail(DG_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = ensure_workspace(h, N);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)N * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // the loss is discarded here: every row is compared with one all-zero image (R = N -> image 0)
+    run_forward(h, h->xzero, N, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, s, false);
+    HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)N * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipGetLastError());
+    return DG_OK;
+}
+
+int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, float* out_y, float* out_loss,
+                 float* out_dz, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (!x || !z || B < 1 || R < 1) return fail(DG_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int n_rows = B * R;
+    rc = ensure_workspace(h, n_rows);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    run_forward(h, x, n_rows, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, s, false);
+    if (out_y) HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)n_rows * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_dz) {
+        run_backward(h, n_rows, s, false);
+        dg::launch_momentum_update(nullptr, nullptr, h->part, h->nsplit, n_rows, h->latent, 0.f, 0.f, out_dz, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return DG_OK;
+}
+
+int dg_profile_enable(dg_handle* h, int on) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    h->prof_stride = on > 0 ? on : 0;
+    return DG_OK;
+}
+int dg_profile_count(dg_handle* h) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    prof_collect(h);
+    return (int)h->prof.size();
+}
+int dg_profile_read(dg_handle* h, int i, char* name, int name_len, int64_t* launches, double* total_ms, double* flops) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    prof_collect(h);
+    if (i < 0 || i >= (int)h->prof.size()) return fail(DG_E_INVALID, "profile index out of range");
+    const ProfEntry& p = h->prof[i];
+    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name.c_str());
+    if (launches) *launches = p.launches;
+    if (total_ms) *total_ms = p.ms;
+    if (flops) *flops = p.flops;
+    return DG_OK;
+}
+int dg_profile_reset(dg_handle* h) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    prof_collect(h);
+    h->prof.clear();
+    h->prof_index.clear();
+    return DG_OK;
+}
+
+int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
+    if (!h || !what || !dst) return fail(DG_E_INVALID, "null argument");
+    const std::string w(what);
+    const float* src = nullptr;
+    int64_t avail = 0;
+    if (w == "z") { src = h->z; avail = h->cap_rows * h->latent; }
+    else if (w == "m") { src = h->m; avail = h->cap_rows * h->latent; }
+    else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
+    else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
+    else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
+    else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
+        const int d = w[3] - '0';
+        if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
+    }
+    if (!src) return fail(DG_E_INVALID, "unknown buffer '%s'", what);
+    const int64_t cnt = n < avail ? n : avail;
+    HIP_TRY(hipMemcpy(dst, src, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice));
+    return cnt;
+}
+
+int dg_set_option(dg_handle* h, const char* key, const char* value) {
+    if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
+    const std::string k(key);
+    if (k.compare(0, 5, "tile.") == 0) {
+        const int t = atoi(value);
+        if (t < 0 || t > 3) return fail(DG_E_INVALID, "tile id must be 0..3");
+        h->tile_override[k.substr(5)] = t;
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        int rc = build_plans(h);
+        if (rc) return rc;
+        const size_t ndec = h->dec.size();
+        h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
+        h->B1.W = h->lin_w;
+        for (size_t d = 0; d + 1 < ndec; ++d) {
+            h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
+            h->Bd[d].W = h->Ft[d];
+        }
+        return DG_OK;
+    }
+    if (k == "nsplit") {
+        const int v = atoi(value);
+        if (v < 1 || v > 64 || (h->lin_out / v) % 32 || h->lin_out % v) return fail(DG_E_INVALID, "nsplit must divide lin_out into multiples of 32");
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->nsplit = v;
+        free_workspace(h);
+        return dg_set_option(h, "tile.__rebuild", "0");
+    }
+    return fail(DG_E_INVALID, "unknown option '%s'", key);
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// Gathered implicit-GEMM kernel for gfx950 (MI355X): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Covers Linear fwd/bwd and every 5x5 stride-2 transposed conv fwd / backward-to-input of the
+// Defense-GAN generators (reference call sites: tflib/ops/linear.py:129-142,
+// tflib/ops/deconv2d.py:100-117).  M = latent rows (B*R), N = output channels of ONE output
+// position, K = (valid taps of that position) x (input channels): the tap list is resolved on the
+// host per position (dg_plan.cpp), so border taps are skipped exactly and zeros are never multiplied.
+//
+// Data movement: both operands are K-contiguous in HBM (NHWC activations; filters [tap][n][k]), so a
+// 32-float K chunk of a row is one 128-B line.  Lines go HBM/L2 -> LDS with global_load_lds
+// (16 B/lane, no VGPR round trip), double buffered; the 16-B slot inside each LDS row is XOR-swizzled
+// through the per-lane SOURCE address so the ds_read_b128 fragment reads are bank-conflict free.
+// One b128 fragment read feeds four MFMAs: lane half h = lane>>5 holds k = 8*kk + 4*h + e for
+// e = 0..3, the same K permutation on A and B.
+#include "dg_kernels.h"
+
+namespace dg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+constexpr int BK = 32;                 // floats per K chunk = one 128-B line per row
+constexpr int ROW_BYTES = BK * 4;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
+    constexpr int TM = BM / 64;        // 32x32 sub-tiles per wave (waves are 2 x 2)
+    constexpr int TN = BN / 64;
+    constexpr int SA = BM / 32;        // staging slots (16 B each) per thread, A operand
+    constexpr int SB = BN / 32;
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int pn = blockIdx.x / g.n_mtiles;
+    const int mt = blockIdx.x - pn * g.n_mtiles;
+    const PosEntry pe = g.pos[pn];
+    const int pe_out_off = __builtin_amdgcn_readfirstlane(pe.out_off);
+    const int pe_n0 = __builtin_amdgcn_readfirstlane(pe.n0);
+    const int pe_tap_begin = __builtin_amdgcn_readfirstlane(pe.tap_begin);
+    const int pe_tap_count = __builtin_amdgcn_readfirstlane(pe.tap_count);
+    const int m0 = mt * BM;
+
+    // ---- per-thread staging sources (rows are fixed for the whole tile) -------------------------
+    const float* asrc[SA];
+    const float* wsrc[SB];
+#pragma unroll
+    for (int s = 0; s < SA; ++s) {
+        const int r = (s * 4 + wave) * 8 + (lane >> 3);           // row inside the A tile
+        const int c = (lane & 7) ^ swz(r);                         // source 16-B chunk for LDS slot lane&7
+        int n = m0 + r;
+        n = n < g.n_rows ? n : g.n_rows - 1;                       // ragged M: clamp loads, mask stores
+        asrc[s] = g.A + (long long)n * g.a_rowstride + c * 4;
+    }
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+        const int r = (s * 4 + wave) * 8 + (lane >> 3);           // output column inside the tile
+        const int c = (lane & 7) ^ swz(r);
+        wsrc[s] = g.W + (long long)(pe_n0 + r) * g.w_rowstride + c * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int chunks_per_tap = g.kch / BK;
+    const int nchunks = pe_tap_count * chunks_per_tap;
+    const TapEntry* taps = g.taps + pe_tap_begin;
+
+    int ld_tap = 0, ld_k = 0;
+    auto issue = [&](int stage) {
+        const TapEntry te = taps[ld_tap];
+        const int aoff = __builtin_amdgcn_readfirstlane(te.a_off) + ld_k;
+        const int woff = __builtin_amdgcn_readfirstlane(te.w_off) + ld_k;
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sB = sA + BM * ROW_BYTES;
+#pragma unroll
+        for (int s = 0; s < SA; ++s)
+            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(asrc[s] + aoff),
+                                             DG_LDS_PTR(sA + (s * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int s = 0; s < SB; ++s)
+            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(wsrc[s] + woff),
+                                             DG_LDS_PTR(sB + (s * 4 + wave) * 1024), 16, 0, 0);
+        ld_k += BK;
+        if (ld_k == g.kch) { ld_k = 0; ++ld_tap; }
+    };
+
+    // fragment read addresses (byte offsets inside a stage), fixed per thread
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+    int a_rd[TM], b_rd[TN], a_sw[TM], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + frow;
+        a_rd[i] = r * ROW_BYTES;
+        a_sw[i] = swz(r);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / 2) + j * 32 + frow;
+        b_rd[j] = BM * ROW_BYTES + r * ROW_BYTES;
+        b_sw[j] = swz(r);
+    }
+
+    issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // chunk c landed for every wave; stage (c+1)&1 is free
+        if (c + 1 < nchunks) issue((c + 1) & 1);
+        const char* st = smem + (c & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 a[TM], b[TN];
+            const int chunk = kk * 2 + fh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((chunk ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((chunk ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
+    // Each store instruction writes two 128-B row segments (32 consecutive channels x 2 rows).
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = pe_n0 + wn * (BN / 2) + j * 32 + frow;
+        float bv = 0.f;
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = g.bias[col];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+            float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
+            float oldv[16];
+            if constexpr (MODE == EPI_MASK) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dr = (e & 3) + 8 * (e >> 2);
+                    oldv[e] = (row0 + dr < g.n_rows) ? obase[(long long)dr * g.out_rowstride] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int dr = (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] + bv;
+                if constexpr (MODE == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
+                if constexpr (MODE == EPI_MASK) v = oldv[e] > 0.f ? v : 0.f;
+                if (row0 + dr < g.n_rows) obase[(long long)dr * g.out_rowstride] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int MODE>
+static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
+    constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const unsigned grid = (unsigned)n_pos * (unsigned)a.n_mtiles;
+    hipLaunchKernelGGL((gemm_gather_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, s, a);
+}
+
+template <int BM, int BN>
+static void launch_t(const GemmArgs& a, int n_pos, hipStream_t s) {
+    switch (a.mode) {
+        case EPI_STORE: launch_tm<BM, BN, EPI_STORE>(a, n_pos, s); break;
+        case EPI_BIAS: launch_tm<BM, BN, EPI_BIAS>(a, n_pos, s); break;
+        case EPI_BIAS_RELU: launch_tm<BM, BN, EPI_BIAS_RELU>(a, n_pos, s); break;
+        default: launch_tm<BM, BN, EPI_MASK>(a, n_pos, s); break;
+    }
+}
+
+static const int kTileBM[4] = {128, 64, 128, 64};
+static const int kTileBN[4] = {128, 128, 64, 64};
+int gemm_tile_bm(int tile) { return kTileBM[tile & 3]; }
+int gemm_tile_bn(int tile) { return kTileBN[tile & 3]; }
+
+void launch_gemm(int tile, const GemmArgs& a, int n_pos, hipStream_t s) {
+    switch (tile & 3) {
+        case 0: launch_t<128, 128>(a, n_pos, s); break;
+        case 1: launch_t<64, 128>(a, n_pos, s); break;
+        case 2: launch_t<128, 64>(a, n_pos, s); break;
+        default: launch_t<64, 64>(a, n_pos, s); break;
+    }
+}
+
+}  // namespace dg

@@ -1,0 +1,106 @@
+// Device-kernel launch interface of the projection engine (gfx950 only).
+// Host code (dg_engine.cpp) fills these argument blocks from the layer plans (dg_plan.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "dg_types.h"
+
+namespace dg {
+
+// ---- gathered implicit GEMM -------------------------------------------------------------------
+// Out[n, pos, n0 + c] = epi( sum_{t in taps(pos)} sum_{k < kch} A[n*a_rowstride + a_off(t) + k]
+//                                                          * W[w_off(t) + (n0 + c)*w_rowstride + k] )
+// One workgroup = (M tile of BM latent rows) x (one output position) x (BN output columns).
+// Used for: Linear fwd/bwd (tflib/ops/linear.py:129-142), every Deconv2D fwd
+// (tf.nn.conv2d_transpose, tflib/ops/deconv2d.py:100-117) and its backward-to-input (a stride-2
+// SAME conv), with the 5x5 taps resolved per output position so that no zero is ever multiplied.
+enum EpiMode : int {
+    EPI_STORE = 0,       // out = acc
+    EPI_BIAS = 1,        // out = acc + bias[col]
+    EPI_BIAS_RELU = 2,   // out = max(acc + bias[col], 0)          (BiasAdd + Relu)
+    EPI_MASK = 3,        // out = out_old > 0 ? acc : 0            (ReluGrad, in place over the activation)
+};
+
+struct GemmArgs {
+    const float* A;
+    const float* W;
+    float* Out;
+    const float* bias;
+    const PosEntry* pos;
+    const TapEntry* taps;
+    long long a_rowstride;
+    long long out_rowstride;
+    int w_rowstride;
+    int kch;             // K extent per tap, multiple of 32
+    int n_rows;
+    int n_mtiles;
+    int mode;
+};
+
+// tile shapes: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64  (BM x BN)
+void launch_gemm(int tile, const GemmArgs& a, int n_pos, hipStream_t s);
+int gemm_tile_bm(int tile);
+int gemm_tile_bn(int tile);
+
+// ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
+// dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.
+struct MnistTailArgs {
+    float* h3;           // [N,14,14,C] in: relu output; out (if backward): da3 = dh3 * [h3 > 0]
+    const float* F5;     // [5,5,1,C]
+    const float* b5;     // [1]
+    const float* x;      // [B,28,28,1]
+    float* loss;         // [N]
+    float* y;            // [N,784] or nullptr
+    int n_rows;
+    int R;
+    int C;               // net_dim (64)
+    int do_backward;
+};
+void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);
+
+// ---- CelebA tail: Generator.6 (64 -> 3, 64x64) + tanh + loss + backward to da5 ----------------
+struct CelebaTailArgs {
+    float* h5;           // [N,32,32,C] in: Generator.5 output (no nonlinearity); out: da5
+    const float* F6;     // [5,5,3,C]
+    const float* b6;     // [3]
+    const float* x;      // [B,64,64,3]
+    float* loss_part;    // [N, 16] per-band partial sums of squared error
+    float* y;            // [N,64,64,3] or nullptr
+    float* g6;           // [N,64,64,3] scratch for da6 (needed across band borders)
+    int n_rows;
+    int R;
+    int C;
+    int do_backward;
+};
+void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s);
+void launch_celeba_tail_bwd(const CelebaTailArgs& a, hipStream_t s);
+void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s);
+
+// ---- small kernels ----------------------------------------------------------------------------
+// m = momentum*m + sum_s part[n][s][:];  z -= lr*m     (ApplyMomentum, gan.py:389-391)
+void launch_momentum_update(float* z, float* m, const float* part, int nsplit, int64_t n_elems_rows,
+                            int latent, float lr, float momentum, float* dz_out, hipStream_t s);
+// first-argmin over R restarts + gather (gan.py:438-449)
+void launch_select(const float* loss, const float* y, int B, int R, int P, float* out_rec, int32_t* out_idx,
+                   hipStream_t s);
+// z ~ N(0, std^2), Philox4x32-10 keyed by (seed), counter (global row, column/4)
+void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, int64_t first_row, float std,
+                         hipStream_t s);
+void launch_fill_zero(float* p, int64_t n, hipStream_t s);
+
+// ---- BatchNorm with batch statistics (tflib/ops/batchnorm.py:80-93) ---------------------------
+// a [rows, C] viewed as rows x C (rows = N*positions); per-column mean / biased variance, eps 1e-5.
+struct BnArgs {
+    float* a;            // in: pre-activation; out: relu(bn(a))  (fwd) | in: dh, out: da (bwd)
+    float* xhat;         // [rows, C] normalised activations saved by fwd
+    float* rstd;         // [C]
+    const float* scale;  // [C]
+    const float* offset; // [C]
+    float* stats;        // [2, C] scratch (sum, sumsq) / (sum dy, sum dy*xhat)
+    int64_t rows;
+    int C;
+};
+void launch_bn_forward(const BnArgs& a, hipStream_t s);      // stats + normalise + ReLU, keeps xhat
+void launch_bn_backward(const BnArgs& a, const float* h_act, hipStream_t s);
+
+}  // namespace dg

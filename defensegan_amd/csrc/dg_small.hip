@@ -1,0 +1,130 @@
+// Small kernels of the projection loop (gfx950): momentum update, restart selection, latent init.
+#include "dg_kernels.h"
+
+namespace dg {
+
+// ---- ApplyMomentum (tf.train.MomentumOptimizer, non-Nesterov; gan.py:389-391, 416-417) ------------
+//   g = sum_s part[n][s][d]  (split-K partials of dz = da1 . W^T, fixed summation order)
+//   m <- momentum*m + g ;  z <- z - lr*m
+__global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ z, float* __restrict__ m,
+                                                              const float* __restrict__ part, int nsplit,
+                                                              long long n_rows, int latent, float lr,
+                                                              float momentum, float* __restrict__ dz_out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = n_rows * latent;
+    if (i >= total) return;
+    const long long n = i / latent;
+    const int d = (int)(i - n * latent);
+    const float* p = part + n * (long long)nsplit * latent + d;
+    float g = 0.f;
+    for (int s = 0; s < nsplit; ++s) g += p[(long long)s * latent];
+    if (dz_out) { dz_out[i] = g; return; }
+    const float mm = momentum * m[i] + g;
+    m[i] = mm;
+    z[i] = z[i] - lr * mm;
+}
+
+void launch_momentum_update(float* z, float* m, const float* part, int nsplit, int64_t n_rows, int latent,
+                            float lr, float momentum, float* dz_out, hipStream_t s) {
+    const long long total = (long long)n_rows * latent;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(momentum_update_kernel, dim3(grid), dim3(256), 0, s, z, m, part, nsplit,
+                       (long long)n_rows, latent, lr, momentum, dz_out);
+}
+
+// ---- selection: first argmin over the R restarts of each image, then gather (gan.py:438-449) ------
+__global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ loss, const float* __restrict__ y,
+                                                    int R, int P, float* __restrict__ out_rec,
+                                                    int32_t* __restrict__ out_idx) {
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    float best = __builtin_inff();
+    int bi = 0x7fffffff;
+    for (int r = lane; r < R; r += 64) {
+        const float v = loss[(long long)b * R + r];
+        // strict "<" keeps the first minimum; a NaN loss never wins (all-NaN rows select restart 0)
+        if (v < best || (v == best && r < bi)) { best = v; bi = r; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (bi == 0x7fffffff) bi = 0;
+    if (lane == 0 && out_idx) out_idx[b] = bi;
+    const float* src = y + ((long long)b * R + bi) * P;
+    float* dst = out_rec + (long long)b * P;
+    for (int i = lane; i < P; i += 64) dst[i] = src[i];
+}
+
+void launch_select(const float* loss, const float* y, int B, int R, int P, float* out_rec, int32_t* out_idx,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(64), 0, s, loss, y, R, P, out_rec, out_idx);
+}
+
+// ---- latent init: z ~ N(0, std^2), Philox4x32-10 + Box-Muller ------------------------------------
+// counter = (global row lo, global row hi, column/4, 0), key = (seed lo, seed hi): the draw of a row
+// depends only on (seed, global row), never on batching or on the GPU count.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void init_latents_kernel(float* __restrict__ z, long long n_rows, int latent,
+                                                           unsigned long long seed, long long first_row,
+                                                           float std) {
+    const int q = latent / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * q) return;
+    const long long row = i / q;
+    const int cq = (int)(i - row * q);
+    const unsigned long long grow = (unsigned long long)(first_row + row);
+    uint32_t c[4] = {(uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)cq, 0u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    // uniforms in (0,1]: (x + 1) * 2^-32
+    const float u0 = ((float)c[0] + 1.0f) * 2.3283064365386963e-10f;
+    const float u1 = ((float)c[1] + 1.0f) * 2.3283064365386963e-10f;
+    const float u2 = ((float)c[2] + 1.0f) * 2.3283064365386963e-10f;
+    const float u3 = ((float)c[3] + 1.0f) * 2.3283064365386963e-10f;
+    const float r0 = sqrtf(-2.0f * logf(u0 < 1.0f ? u0 : 1.0f)) * std;
+    const float r1 = sqrtf(-2.0f * logf(u2 < 1.0f ? u2 : 1.0f)) * std;
+    const float t0 = 6.283185307179586f * u1;
+    const float t1 = 6.283185307179586f * u3;
+    float4 o;
+    o.x = r0 * cosf(t0);
+    o.y = r0 * sinf(t0);
+    o.z = r1 * cosf(t1);
+    o.w = r1 * sinf(t1);
+    *reinterpret_cast<float4*>(z + row * latent + cq * 4) = o;
+}
+
+void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, int64_t first_row, float std,
+                         hipStream_t s) {
+    const long long total = (long long)n_rows * (latent / 4);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(init_latents_kernel, dim3(grid), dim3(256), 0, s, z, (long long)n_rows, latent,
+                       (unsigned long long)seed, (long long)first_row, std);
+}
+
+__global__ __launch_bounds__(256) void fill_zero_kernel(float* p, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+void launch_fill_zero(float* p, int64_t n, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (long long)n);
+}
+
+}  // namespace dg

@@ -1,0 +1,349 @@
+"""Host-side mirror of the reference's GAN model object for the latent-projection path.
+
+Keeps the surface of ``DefenseGANBase`` (/root/reference/models/gan.py:39-647) that the callers of
+the hot path use -- ``GAN(cfg, test_mode=True)``, ``.load_generator()``, ``.reconstruct(images,
+batch_size, back_prop, reconstructor_id, z_init_val)``, attributes ``rec_iters / rec_rr / rec_lr /
+latent_dim / net_dim / use_bn / image_dim / batch_size / dataset_name`` -- and forwards the work to
+the hand-written HIP engine through the C ABI (include/defensegan_hip.h).  Arrays replace TF tensors:
+NumPy in -> NumPy out, torch in -> torch (on the engine's device) out.
+
+Differences from the reference that are deliberate:
+* stateless per call: fresh z0 / zero momentum every batch (what ``model_eval_gan`` arranges with
+  ``tf.local_variables_initializer()``, utils/gan_defense.py:119); no warm start across batches;
+* ragged last batches are accepted (the reference's static graph needs exactly ``batch_size`` images);
+* the learning rate is the constant ``rec_lr`` -- what the reference executes, because the decay's
+  step variable is never advanced (gan.py:362-386, base_model.py:188-192).
+There is no CPU fallback: without the HIP library / a GPU every compute method raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _native, archs, config as _config
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class DefenseGANBase(object):
+    arch_name = None          # set by subclasses
+
+    _default_attributes = ['dataset_name', 'batch_size', 'use_bn', 'test_batch_size', 'latent_dim',
+                           'net_dim', 'rec_iters', 'image_dim', 'rec_rr', 'rec_lr', 'debug']
+
+    def __init__(self, cfg=None, test_mode=False, verbose=False, device=None, **args):
+        # defaults of DefenseGANBase.__init__ (gan.py:50-68)
+        self.dataset_name = None
+        self.batch_size = 32
+        self.use_bn = True
+        self.test_batch_size = 20
+        self.latent_dim = None
+        self.net_dim = None
+        self.debug = False
+        self.rec_iters = 200
+        self.image_dim = [None, None, None]
+        self.rec_rr = 10
+        self.rec_lr = 10.0
+        self.rec_momentum = 0.7            # hard-coded in the reference (gan.py:390)
+        self.test_mode = test_mode
+        self.verbose = verbose
+        self.cfg = dict(cfg) if cfg else {}
+        self.initialized = False
+        # attribute resolution order of AbstractModel._set_attr (base_model.py:120-148):
+        # explicit keyword > cfg[UPPER] > cfg[lower] > class default
+        for name in self._default_attributes:
+            val = args.get(name)
+            if val is None:
+                if name.upper() in self.cfg:
+                    val = self.cfg[name.upper()]
+                elif name.lower() in self.cfg:
+                    val = self.cfg[name.lower()]
+            if val is not None:
+                setattr(self, name, val)
+        if self.latent_dim is None:
+            self.latent_dim = 128
+        if self.net_dim is None:
+            self.net_dim = 64
+        self._arch = archs.make_arch(self.arch_name or self.dataset_name, int(self.latent_dim), int(self.net_dim))
+        if self.image_dim is None or self.image_dim[0] is None:
+            self.image_dim = list(self._arch.image_dim)
+        if list(self.image_dim) != list(self._arch.image_dim):
+            raise ValueError("image_dim %r does not match the %s generator (%r)" %
+                             (self.image_dim, self._arch.name, self._arch.image_dim))
+        if test_mode:
+            self.test_batch_size = self.batch_size        # gan.py:105
+        self._device = device
+        self._handle = None
+        self._weights: Dict[str, np.ndarray] = {}
+        self._default_seed = 11241990                     # whitebox.py:143 / blackbox.py:464
+        self._calls = 0
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _ensure_handle(self):
+        if self._handle is not None:
+            return self._handle
+        torch = _torch()
+        lib = _native.load()
+        if not torch.cuda.is_available():
+            raise _native.NativeError("no GPU visible: the projection engine has no CPU fallback")
+        dev = self._device
+        if dev is None:
+            dev = torch.cuda.current_device()
+        if isinstance(dev, str):
+            dev = torch.device(dev)
+        if hasattr(dev, "index"):
+            dev = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._device = int(dev)
+        h = C.c_void_p()
+        _native.check(lib.dg_create(self._arch.arch_id, int(self.latent_dim), int(self.net_dim),
+                                    1 if self.use_bn else 0, self._device, C.byref(h)))
+        self._handle = h
+        for k, v in self._weights.items():
+            self._push_weight(k, v)
+        return h
+
+    def _push_weight(self, name: str, arr: np.ndarray):
+        lib = _native.load()
+        a = np.ascontiguousarray(arr, dtype=np.float32)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        _native.check(lib.dg_set_weights(self._handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape,
+                                         a.ndim, 0))
+
+    def close(self):
+        if self._handle is not None:
+            _native.load().dg_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def set_weights(self, weights: Dict[str, np.ndarray]):
+        """weights: tflib parameter name -> array in the reference layout
+        (tflib/__init__.py:9-33; names listed in include/defensegan_hip.h)."""
+        want = archs.weight_shapes(self._arch, bool(self.use_bn))
+        for k, v in weights.items():
+            if k not in want:
+                continue
+            if tuple(v.shape) != tuple(want[k]):
+                raise ValueError("%s: shape %r, expected %r" % (k, tuple(v.shape), want[k]))
+            self._weights[k] = np.ascontiguousarray(v, np.float32)
+            if self._handle is not None:
+                self._push_weight(k, self._weights[k])
+        missing = [k for k in want if k not in self._weights]
+        self.initialized = not missing
+        return missing
+
+    def load_generator(self, ckpt_path: Optional[str] = None):
+        """Counterpart of ``load_generator`` (gan.py:85-87).  ``ckpt_path`` is an ``.npz`` weight pack whose
+        keys are the tflib parameter names (a TF1 checkpoint has to be converted on a TF-capable machine:
+        TensorFlow is not available here)."""
+        if ckpt_path is None:
+            raise ValueError("load_generator needs the path of an .npz weight pack")
+        if os.path.isdir(ckpt_path):
+            ckpt_path = os.path.join(ckpt_path, "generator.npz")
+        with np.load(ckpt_path) as f:
+            missing = self.set_weights({k: f[k] for k in f.files})
+        if missing:
+            raise ValueError("weight pack %s lacks %s" % (ckpt_path, ", ".join(missing)))
+        return True
+
+    # ------------------------------------------------------------------ the hot path
+    def input_transform(self, X):
+        """[0,255] -> generator range: /255 for MNIST / F-MNIST (gan.py:684-685, 697-698),
+        2*(x/255 - .5) for CelebA (gan.py:764-765)."""
+        if self._arch.arch_id == archs.ARCH_CELEBA:
+            return 2.0 * (X / 255.0 - 0.5)
+        return X / 255.0
+
+    def _to_device(self, a, dtype=None):
+        torch = _torch()
+        dev = torch.device("cuda", self._device)
+        if isinstance(a, np.ndarray):
+            t = torch.from_numpy(np.ascontiguousarray(a))
+        else:
+            t = a
+        t = t.to(device=dev, dtype=dtype or torch.float32)
+        return t.contiguous()
+
+    def reconstruct(self, images, batch_size=None, back_prop=True, reconstructor_id=0, z_init_val=None,
+                    seed=None, first_row=0, return_details=False):
+        """Defense-GAN projection of ``images`` [B,H,W,C] (already in generator range).
+
+        Same arguments as the reference (gan.py:333-335).  ``batch_size`` only validates the leading
+        dimension when given (the reference needs it for its static graph); ``back_prop`` is accepted and
+        ignored -- the reference's gradient through this op is identically zero;
+        ``reconstructor_id`` only named TF variables.  ``z_init_val`` [B*rec_rr, latent] fixes z0
+        (row b*rec_rr + r, gan.py:348-359, 395-397); otherwise rows are drawn N(0, 1/latent) on the
+        device from (seed, first_row + row).  Returns the reconstructions [B,H,W,C]; with
+        ``return_details`` a dict with rec, idx [B], loss [B*R], z [B*R, latent].
+        """
+        self._ensure_handle()
+        if not self.initialized:
+            raise _native.NativeError("generator weights not loaded (load_generator / set_weights)")
+        torch = _torch()
+        lib = _native.load()
+        was_numpy = isinstance(images, np.ndarray)
+        x = self._to_device(images)
+        H, W, Cc = self._arch.image_dim
+        if x.dim() == 2 and x.shape[1] == H * W * Cc:
+            x = x.view(-1, H, W, Cc)
+        if x.dim() != 4 or tuple(x.shape[1:]) != (H, W, Cc):
+            raise ValueError("images must be [B,%d,%d,%d], got %r" % (H, W, Cc, tuple(x.shape)))
+        B = int(x.shape[0])
+        if batch_size is not None and B > int(batch_size):
+            raise ValueError("got %d images for batch_size=%d" % (B, batch_size))
+        R, L = int(self.rec_rr), int(self.rec_iters)
+        n_rows = B * R
+        z0 = None
+        if z_init_val is not None:
+            z0 = self._to_device(z_init_val)
+            if tuple(z0.shape) != (n_rows, int(self.latent_dim)):
+                raise ValueError("z_init_val must be [%d,%d], got %r" % (n_rows, self.latent_dim, tuple(z0.shape)))
+        if seed is None:
+            seed = self._default_seed + self._calls
+        self._calls += 1
+        dev = x.device
+        rec = torch.empty_like(x)
+        idx = torch.empty(B, dtype=torch.int32, device=dev)
+        loss = torch.empty(n_rows, dtype=torch.float32, device=dev)
+        zout = torch.empty(n_rows, int(self.latent_dim), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _native.check(lib.dg_reconstruct(
+                self._handle, x.data_ptr(), z0.data_ptr() if z0 is not None else None,
+                int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_row), B, R, L, float(self.rec_lr), float(self.rec_momentum),
+                rec.data_ptr(), idx.data_ptr(), loss.data_ptr(), zout.data_ptr(), stream))
+        if return_details:
+            out = {"rec": rec, "idx": idx, "loss": loss, "z": zout}
+            if was_numpy:
+                out = {k: v.cpu().numpy() for k, v in out.items()}
+            return out
+        return rec.cpu().numpy() if was_numpy else rec
+
+    def generate(self, z):
+        """G(z): generator_fn(z, is_training=False) (gan.py:399)."""
+        self._ensure_handle()
+        torch = _torch()
+        lib = _native.load()
+        was_numpy = isinstance(z, np.ndarray)
+        zz = self._to_device(z)
+        N = int(zz.shape[0])
+        H, W, Cc = self._arch.image_dim
+        y = torch.empty(N, H, W, Cc, dtype=torch.float32, device=zz.device)
+        with torch.cuda.device(zz.device):
+            _native.check(lib.dg_generate(self._handle, zz.data_ptr(), N, y.data_ptr(),
+                                          torch.cuda.current_stream(zz.device).cuda_stream))
+        return y.cpu().numpy() if was_numpy else y
+
+    def loss_grad(self, images, z):
+        """One loop body without the update: (y [B*R,H,W,C], loss [B*R], dz [B*R, latent])
+        for images [B,...] and z [B*R, latent] (gan.py:409-417)."""
+        self._ensure_handle()
+        torch = _torch()
+        lib = _native.load()
+        was_numpy = isinstance(images, np.ndarray)
+        x = self._to_device(images)
+        zz = self._to_device(z)
+        B = int(x.shape[0])
+        R = int(zz.shape[0]) // B
+        if R * B != int(zz.shape[0]):
+            raise ValueError("z rows must be a multiple of the image count")
+        H, W, Cc = self._arch.image_dim
+        y = torch.empty(B * R, H, W, Cc, dtype=torch.float32, device=x.device)
+        loss = torch.empty(B * R, dtype=torch.float32, device=x.device)
+        dz = torch.empty_like(zz)
+        with torch.cuda.device(x.device):
+            _native.check(lib.dg_loss_grad(self._handle, x.data_ptr(), zz.data_ptr(), B, R, y.data_ptr(),
+                                           loss.data_ptr(), dz.data_ptr(),
+                                           torch.cuda.current_stream(x.device).cuda_stream))
+        if was_numpy:
+            return y.cpu().numpy(), loss.cpu().numpy(), dz.cpu().numpy()
+        return y, loss, dz
+
+    def init_latents(self, n_rows, seed=0, first_row=0, std=None):
+        self._ensure_handle()
+        torch = _torch()
+        lib = _native.load()
+        dev = torch.device("cuda", self._device)
+        z = torch.empty(int(n_rows), int(self.latent_dim), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _native.check(lib.dg_init_latents(self._handle, z.data_ptr(), int(n_rows), int(seed), int(first_row),
+                                              float(std) if std else 0.0,
+                                              torch.cuda.current_stream(dev).cuda_stream))
+        return z
+
+    # ------------------------------------------------------------------ measurement hooks
+    def set_option(self, key: str, value) -> None:
+        self._ensure_handle()
+        _native.check(_native.load().dg_set_option(self._handle, key.encode(), str(value).encode()))
+
+    def profile_enable(self, stride: int) -> None:
+        self._ensure_handle()
+        _native.check(_native.load().dg_profile_enable(self._handle, int(stride)))
+
+    def profile_reset(self) -> None:
+        self._ensure_handle()
+        _native.check(_native.load().dg_profile_reset(self._handle))
+
+    def profile_read(self):
+        """[{name, launches, ms, flops}] per kernel family since the last reset."""
+        self._ensure_handle()
+        lib = _native.load()
+        n = lib.dg_profile_count(self._handle)
+        out = []
+        for i in range(max(n, 0)):
+            name = C.create_string_buffer(64)
+            launches = C.c_int64()
+            ms = C.c_double()
+            fl = C.c_double()
+            _native.check(lib.dg_profile_read(self._handle, i, name, 64, C.byref(launches), C.byref(ms), C.byref(fl)))
+            out.append({"name": name.value.decode(), "launches": launches.value, "ms": ms.value, "flops": fl.value})
+        return out
+
+    def debug_read(self, what: str, n: int):
+        self._ensure_handle()
+        torch = _torch()
+        dev = torch.device("cuda", self._device)
+        torch.cuda.synchronize(dev)
+        t = torch.empty(int(n), dtype=torch.float32, device=dev)
+        got = _native.load().dg_debug_read(self._handle, what.encode(), t.data_ptr(), int(n))
+        if got < 0:
+            _native.check(int(got))
+        return t[:got]
+
+
+class MnistDefenseGAN(DefenseGANBase):          # gan.py:649-685
+    arch_name = "mnist"
+
+
+class FmnistDefenseDefenseGAN(MnistDefenseGAN):  # gan.py:688-698 (same generator, other weights; name sic)
+    arch_name = "f-mnist"
+
+
+class CelebADefenseGAN(DefenseGANBase):         # gan.py:717-765
+    arch_name = "celeba"
+
+
+# whitebox.py / blackbox.py pick the class by FLAGS.dataset_name
+dataset_gan_dict = {
+    "mnist": MnistDefenseGAN,
+    "f-mnist": FmnistDefenseDefenseGAN,
+    "celeba": CelebADefenseGAN,
+}
+
+
+def gan_from_config(cfg_path: str, test_mode: bool = True, **overrides) -> DefenseGANBase:
+    """``GAN(cfg=load_config(path), test_mode=True)`` as whitebox.py:239-244 does."""
+    cfg = _config.load_config(cfg_path)
+    cls = dataset_gan_dict[str(cfg.get("DATASET_NAME", overrides.get("dataset_name", "mnist"))).lower()]
+    return cls(cfg=cfg, test_mode=test_mode, **overrides)

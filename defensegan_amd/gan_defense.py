@@ -1,0 +1,119 @@
+"""Evaluation harness around the projection path: counterpart of ``model_eval_gan``
+(/root/reference/utils/gan_defense.py:32-179) plus the batch-sharded multi-GPU driver.
+
+``model_eval_gan`` in the reference feeds ``test_images`` batch by batch, re-initialises the latent
+variables before every batch (gan_defense.py:119), accumulates the number of correct predictions and
+returns ``accuracy, roc_info=[labels, preds, diffs]`` (gan_defense.py:166-179).  Here the classifier is
+any callable ``images -> logits/probabilities`` (torch or NumPy) and ``reconstruct`` is the engine's
+``DefenseGANBase.reconstruct``; arrays replace the TF placeholders.
+
+Multi-GPU: images are independent (use_bn=False), so the image list is sharded contiguously over the
+ranks of a ``torch.distributed`` group (one process per GPU, RCCL over xGMI on ROCm; gloo on CPU) with
+no collective on the data path and ONE all_gather of (labels, preds, diffs) at the end.  z0 rows are
+keyed by the GLOBAL image index, so results do not depend on the GPU count.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous, balanced shard [start, end) of ``n_items`` for ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(int(n_items), int(world_size))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _np(a):
+    if isinstance(a, np.ndarray):
+        return a
+    return a.detach().cpu().numpy()
+
+
+def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_images, test_labels,
+                   batch_size: int, rec_rr: int = 1, compute_diffs: bool = True, seed: int = 11241990,
+                   first_image: int = 0, same_init_z: Optional[np.ndarray] = None,
+                   verbose: bool = False):
+    """Accuracy of ``classifier(reconstruct(x))`` over ``test_images`` + reconstruction errors.
+
+    reconstruct : ``f(images, z_init_val=None, seed=..., first_row=...) -> reconstructions`` or None
+                  (no defense: the classifier sees the inputs).
+    test_labels : class indices [n] or one-hot [n, classes] (the reference takes argmax, gan_defense.py:91-99)
+    Returns ``(correct_count, n, roc_info)`` with ``roc_info = [labels, preds, diffs]``;
+    ``diffs[i] = mean((x_i - rec_i)^2)`` (diff_op of whitebox.py:218 / blackbox.py:571-572).
+    Accuracy = correct_count / n (gan_defense.py:166) -- kept as a count so shards can be summed.
+    """
+    n = len(test_images)
+    labels = _np(test_labels)
+    if labels.ndim > 1:
+        labels = labels.argmax(axis=-1)
+    nb_batches = int(math.ceil(float(n) / batch_size))
+    preds: List[np.ndarray] = []
+    diffs: List[np.ndarray] = []
+    correct = 0
+    for batch in range(nb_batches):
+        start = batch * batch_size
+        end = min(n, start + batch_size)          # last batch may be smaller (gan_defense.py:124-130)
+        x = test_images[start:end]
+        if reconstruct is not None:
+            kw = {}
+            if same_init_z is not None:
+                kw["z_init_val"] = same_init_z[: (end - start) * rec_rr]
+            rec = reconstruct(x, seed=seed, first_row=(first_image + start) * rec_rr, **kw)
+        else:
+            rec = x
+        out = _np(classifier(rec))
+        p = out.argmax(axis=-1) if out.ndim > 1 else out.astype(np.int64)
+        preds.append(p.astype(np.int64))
+        correct += int((p == labels[start:end]).sum())
+        if compute_diffs:
+            xr, rr = _np(x).reshape(end - start, -1), _np(rec).reshape(end - start, -1)
+            diffs.append(((xr - rr) ** 2).mean(axis=1).astype(np.float32))
+        if verbose:
+            print("[#] Eval batch {}/{}".format(batch, nb_batches))
+    preds_all = np.concatenate(preds) if preds else np.zeros(0, np.int64)
+    diffs_all = np.concatenate(diffs) if diffs else np.zeros(0, np.float32)
+    return correct, n, [labels.astype(np.int64), preds_all, diffs_all]
+
+
+def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, batch_size: int, rec_rr: int = 1,
+                           group=None, device=None, **kw):
+    """Batch-sharded evaluation over a torch.distributed group: every rank evaluates its contiguous shard,
+    then ONE all_gather (padded to the largest shard) assembles ``roc_info`` in global image order.
+    Returns ``(accuracy, roc_info)`` identically on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized():
+        c, n, roc = model_eval_gan(reconstruct, classifier, test_images, test_labels, batch_size, rec_rr, **kw)
+        return c / max(n, 1), roc
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n_total = len(test_images)
+    s, e = shard_range(n_total, rank, world)
+    c, n, roc = model_eval_gan(reconstruct, classifier, test_images[s:e], _np(test_labels)[s:e], batch_size, rec_rr,
+                               first_image=s, **kw)
+    cap = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    # one message per rank: [count, labels.., preds.., diffs..] as float64 (exact for these integers)
+    buf = torch.zeros(1 + 3 * cap, dtype=torch.float64, device=device)
+    buf[0] = n
+    buf[1:1 + n] = torch.from_numpy(roc[0].astype(np.float64))
+    buf[1 + cap:1 + cap + n] = torch.from_numpy(roc[1].astype(np.float64))
+    if len(roc[2]):
+        buf[1 + 2 * cap:1 + 2 * cap + n] = torch.from_numpy(roc[2].astype(np.float64))
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    labels, preds, diffs = [], [], []
+    for t in out:
+        t = t.cpu().numpy()
+        k = int(t[0])
+        labels.append(t[1:1 + k].astype(np.int64))
+        preds.append(t[1 + cap:1 + cap + k].astype(np.int64))
+        diffs.append(t[1 + 2 * cap:1 + 2 * cap + k].astype(np.float32))
+    labels, preds, diffs = np.concatenate(labels), np.concatenate(preds), np.concatenate(diffs)
+    acc = float((labels == preds).sum()) / max(n_total, 1)
+    return acc, [labels, preds, diffs]

@@ -1,0 +1,40 @@
+import os
+
+import numpy as np
+
+from defensegan_amd import archs, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        d = {k: f[k] for k in f.files}
+    for k in ("arch",):
+        d[k] = str(d[k])
+    for k in ("wseed", "R", "L"):
+        d[k] = int(d[k])
+    for k in ("gain", "bias_range", "lr", "momentum"):
+        d[k] = float(d[k])
+    return d
+
+
+def make_gan(arch="mnist", wseed=1234, gain=2.0, bias_range=0.1, rec_rr=10, rec_iters=200, rec_lr=10.0, **kw):
+    from defensegan_amd.gan import dataset_gan_dict
+    a = archs.make_arch(arch)
+    cls = dataset_gan_dict[{"fmnist": "f-mnist"}.get(arch, arch)]
+    gan = cls(cfg={"USE_BN": False, "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim}, test_mode=True,
+              rec_rr=rec_rr, rec_iters=rec_iters, rec_lr=rec_lr, **kw)
+    p = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=bias_range)
+    assert gan.set_weights(p) == []
+    return gan, p
+
+
+def clean_targets(p, arch, B, seed):
+    """x = G(z_true), z_true ~ N(0, 1/latent): clean, in-range targets."""
+    from oracle import defensegan_oracle as O
+    a = archs.make_arch(arch)
+    rs = np.random.RandomState(seed)
+    zt = (rs.standard_normal((B, a.latent_dim)) * np.sqrt(1.0 / a.latent_dim)).astype(np.float32)
+    x, _ = O.generator_forward(p, zt, arch)
+    return x.astype(np.float32), zt

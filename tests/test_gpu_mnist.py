@@ -1,0 +1,184 @@
+"""-m gpu: parity of the HIP projection path (through the C ABI) with the CPU oracle, MNIST / F-MNIST arch."""
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth
+from tests.helpers import clean_targets, load_golden, make_gan
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import defensegan_oracle as O
+    return O
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_native_library_is_loaded():
+    from defensegan_amd import _native
+    lib = _native.load()
+    assert lib.dg_device_count() >= 1
+
+
+@pytest.mark.parametrize("N", [1, 7, 64, 130])
+def test_generate_layers_vs_oracle(N):
+    """Forward parity layer by layer (ragged row counts cross the 64/128-row tile edges)."""
+    O = _oracle()
+    gan, p = make_gan("mnist", bias_range=0.1)
+    rs = np.random.RandomState(N)
+    z = (rs.standard_normal((N, 128)) * 0.3).astype(np.float32)
+    y = gan.generate(z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), "mnist")
+    acts = cache["acts"]
+    for d, name in enumerate(["h1", "h2", "h3"]):
+        got = gan.debug_read("act%d" % d, acts[d].size).cpu().numpy().reshape(acts[d].shape)
+        assert _rel(got, acts[d]) < 2e-6, (name, _rel(got, acts[d]))
+    assert y.shape == (N, 28, 28, 1)
+    np.testing.assert_allclose(y, yo, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,R", [(1, 1), (3, 3), (5, 10), (70, 2)])
+def test_loss_and_gradient_vs_oracle(B, R):
+    """Single loop body: loss, G(z) and dL/dz against the float64 oracle (gate: rel 1e-5)."""
+    O = _oracle()
+    gan, p = make_gan("mnist", gain=3.0, bias_range=0.1)
+    x, _ = clean_targets(p, "mnist", B, seed=5)
+    x = synth.adversarial(x, 0.3, 0.0, 1.0, seed=6)
+    rs = np.random.RandomState(B * 100 + R)
+    z = (rs.standard_normal((B * R, 128)) * 0.2).astype(np.float32)
+    y, loss, dz = gan.loss_grad(x, z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), "mnist")
+    xt = np.repeat(x.astype(np.float64), R, axis=0)
+    lo = ((yo - xt) ** 2).reshape(B * R, -1).mean(axis=1)
+    go = O.generator_backward(p, cache, 2.0 / 784 * (yo - xt), "mnist")
+    np.testing.assert_allclose(y, yo, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(loss, lo, rtol=1e-5)
+    assert _rel(dz, go) < 1e-5, _rel(dz, go)
+
+
+@pytest.mark.parametrize("name", ["mnist_clean_L5", "mnist_adv_L3", "fmnist_clean_L4"])
+def test_reconstruct_matches_golden(name):
+    g = load_golden(name)
+    gan, p = make_gan(g["arch"], wseed=g["wseed"], gain=g["gain"], bias_range=g["bias_range"],
+                      rec_rr=g["R"], rec_iters=g["L"], rec_lr=g["lr"])
+    out = gan.reconstruct(g["x"], z_init_val=g["z0"], return_details=True)
+    np.testing.assert_allclose(out["loss"], g["loss"], rtol=2e-4)
+    np.testing.assert_allclose(out["z"], g["z"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["rec"], g["rec"], rtol=0, atol=2e-5)     # fp32 tolerance of the path
+    assert (out["idx"] == g["idx"]).all()                                   # argmin index bit-exact
+    rec_only = gan.reconstruct(g["x"], z_init_val=g["z0"])
+    np.testing.assert_array_equal(rec_only, out["rec"])
+
+
+def test_schedule_L0_L1_and_tie_break():
+    """L=0 and L=1 return G(z0); identical restarts tie -> the FIRST index wins (gan.py:438-445)."""
+    O = _oracle()
+    B, R = 3, 4
+    gan, p = make_gan("mnist", rec_rr=R, rec_iters=0)
+    x, _ = clean_targets(p, "mnist", B, seed=9)
+    rs = np.random.RandomState(3)
+    z0 = (rs.standard_normal((B * R, 128)) * 0.1).astype(np.float32)
+    z0[0:4] = z0[0]            # image 0: all four restarts identical
+    z0[6] = z0[5]              # image 1: restarts 1 and 2 identical
+    y0 = gan.generate(z0)
+    for L in (0, 1):
+        gan.rec_iters = L
+        out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+        np.testing.assert_array_equal(out["z"], z0)
+        assert out["idx"][0] == 0
+        for b in range(B):
+            np.testing.assert_array_equal(out["rec"][b], y0[b * R + out["idx"][b]])
+            seg = out["loss"][b * R:(b + 1) * R]
+            assert out["idx"][b] == int(np.argmin(seg))
+        assert out["loss"][5] == out["loss"][6]
+    gan.rec_iters = 3
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    assert out["idx"][0] == 0 and out["loss"][0] == out["loss"][3]
+    assert out["loss"][5] == out["loss"][6]
+    assert out["idx"][1] != 2
+
+
+def test_rows_are_independent_of_batching_and_deterministic():
+    """use_bn=False: an image's result must not depend on its batch -- bit for bit."""
+    B, R, L = 37, 3, 6
+    gan, p = make_gan("mnist", rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, "mnist", B, seed=2)
+    z0 = synth.make_z(B * R, 128, seed=4)
+    full = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    again = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    for k in ("rec", "idx", "loss", "z"):
+        np.testing.assert_array_equal(full[k], again[k])
+    cut = 11
+    a = gan.reconstruct(x[:cut], z_init_val=z0[:cut * R], return_details=True)
+    b = gan.reconstruct(x[cut:], z_init_val=z0[cut * R:], return_details=True)
+    np.testing.assert_array_equal(np.concatenate([a["rec"], b["rec"]]), full["rec"])
+    np.testing.assert_array_equal(np.concatenate([a["loss"], b["loss"]]), full["loss"])
+    np.testing.assert_array_equal(np.concatenate([a["idx"], b["idx"]]), full["idx"])
+
+
+def test_seeded_latents_are_shard_independent_and_normal():
+    gan, _ = make_gan("mnist")
+    z = gan.init_latents(4096, seed=77).cpu().numpy()
+    assert abs(z.mean()) < 5e-4 and abs(z.std() - np.sqrt(1 / 128.0)) < 5e-4
+    zb = gan.init_latents(1000, seed=77, first_row=3000).cpu().numpy()
+    np.testing.assert_array_equal(zb, z[3000:4000])
+    assert not np.array_equal(gan.init_latents(16, seed=78).cpu().numpy(), z[:16])
+    # kurtosis of a normal
+    k = ((z / z.std()) ** 4).mean()
+    assert abs(k - 3.0) < 0.05
+    # reconstruct with z0=None is reproducible for a seed and differs across seeds
+    gan.rec_rr, gan.rec_iters = 2, 2
+    x = np.full((3, 28, 28, 1), 0.5, np.float32)
+    r1 = gan.reconstruct(x, seed=5, return_details=True)
+    r2 = gan.reconstruct(x, seed=5, return_details=True)
+    r3 = gan.reconstruct(x, seed=6, return_details=True)
+    np.testing.assert_array_equal(r1["z"], r2["z"])
+    assert not np.array_equal(r1["z"], r3["z"])
+
+
+def test_errors_are_reported():
+    from defensegan_amd import _native
+    from defensegan_amd.gan import MnistDefenseGAN
+    gan = MnistDefenseGAN(cfg={"USE_BN": False}, test_mode=True)
+    with pytest.raises(_native.NativeError):
+        gan.reconstruct(np.zeros((2, 28, 28, 1), np.float32))          # weights not loaded
+    gan2, _ = make_gan("mnist", rec_rr=2, rec_iters=1)
+    with pytest.raises(ValueError):
+        gan2.reconstruct(np.zeros((2, 28, 27, 1), np.float32))
+    with pytest.raises(ValueError):
+        gan2.reconstruct(np.zeros((2, 28, 28, 1), np.float32), z_init_val=np.zeros((3, 128), np.float32))
+
+
+def test_full_size_contractive_regime_properties():
+    """BASELINE config 2 shape (B=256, R=10, L=200): size-independent properties + an oracle subset.
+    Clean in-range targets, gain 2.0: the loop is contractive, so fp32 results are comparable
+    (SURVEY 8c): best-restart loss collapses, argmin matches the oracle, MSE to the oracle < 1e-4."""
+    B, R, L = 256, 10, 200
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, "mnist", B, seed=21)
+    z0 = synth.make_z(B * R, 128, seed=22)
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    loss = out["loss"].reshape(B, R)
+    gan.rec_iters = 1
+    loss0 = gan.reconstruct(x, z_init_val=z0, return_details=True)["loss"].reshape(B, R)
+    assert np.isfinite(out["rec"]).all()
+    assert (loss.min(axis=1) < 0.05 * loss0.min(axis=1)).mean() > 0.95
+    assert (out["idx"] == loss.argmin(axis=1)).all()
+    rows = np.arange(B) * R + out["idx"]
+    gan.rec_iters = L
+    # rec is G(z_{L-1}) of the selected row
+    y_sel = gan.generate(out["z"][rows])
+    np.testing.assert_allclose(out["rec"], y_sel, rtol=0, atol=1e-6)
+    # oracle on the first 3 images (rows are independent, so a subset is a valid check)
+    from oracle import torch_ref as T
+    nb = 3
+    t = T.reconstruct(p, x[:nb], z0[:nb * R], R, L, lr=10.0, momentum=0.7, arch="mnist")
+    mse = ((out["rec"][:nb] - t["rec"]) ** 2).reshape(nb, -1).mean(axis=1)
+    assert (mse < 1e-4).all(), mse
+    gap = np.sort(t["loss"].reshape(nb, R), axis=1)
+    decided = (gap[:, 1] - gap[:, 0]) > 1e-6          # compare argmin only where the top-2 gap is resolvable
+    assert (out["idx"][:nb][decided] == t["idx"][decided]).all()
+    np.testing.assert_allclose(out["loss"][:nb * R], t["loss"], rtol=0.05, atol=2e-6)
