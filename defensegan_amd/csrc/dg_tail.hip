@@ -14,7 +14,8 @@ namespace dg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HP = 16;           // padded h3 extent (14 + 2)
-constexpr int GW = 32;           // padded g5 row pitch (30 used)
+constexpr int GW = 32;           // padded g5 row pitch (31 used: i+1 for i in [-1, 29])
+constexpr int GR = 31;           // padded g5 rows
 
 template <int PI, int PJ>
 __device__ __forceinline__ float tail_fwd_pixel(const float* sh3, const f32x4 (&w)[25], int C, int ti, int tj,
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256) void mnist_tail_kernel(MnistTailArgs a) {
     constexpr int SLOTS = 256 / G;       // pixels / positions processed concurrently
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sh3 = reinterpret_cast<float*>(smem);                 // [16][16][C], zero border
-    float* sg = sh3 + HP * HP * C;                               // [30][GW] da5, zero border
-    float* sred = sg + 30 * GW;                                  // [4]
+    float* sg = sh3 + HP * HP * C;                               // [GR][GW] da5, zero border
+    float* sred = sg + GR * GW;                                  // [4]
 
     const int tid = threadIdx.x;
     const int n = blockIdx.x;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void mnist_tail_kernel(MnistTailArgs a) {
     float* hrow = a.h3 + (long long)n * (196 * C);
 
     // ---- stage: zero the border + sg, copy the 14x14xC interior ----------------------------------
-    for (int i = tid; i < 30 * GW; i += 256) sg[i] = 0.f;
+    for (int i = tid; i < GR * GW; i += 256) sg[i] = 0.f;
     for (int i = tid; i < 60 * G; i += 256) {
         const int bp = i / G, g = i % G;
         int ph, pw;                                              // 60 border positions of the 16x16 frame
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void mnist_tail_kernel(MnistTailArgs a) {
             if (valid && c4 == 0) {
                 const int i = 2 * ti + pi, j = 2 * tj + pj;
                 const float pre = s + bias;
-                const float y = 1.0f / (1.0f + __expf(-pre));
+                const float y = 1.0f / (1.0f + expf(-pre));
                 const float d = y - xrow[i * 28 + j];
                 sq = __builtin_fmaf(d, d, sq);
                 sg[(i + 1) * GW + (j + 1)] = gscale * d * y * (1.0f - y);
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void mnist_tail_kernel(MnistTailArgs a) {
 
 template <int C>
 static void launch_tail_c(const MnistTailArgs& a, hipStream_t s) {
-    constexpr int lds = (HP * HP * C + 30 * GW + 4) * 4;
+    constexpr int lds = (HP * HP * C + GR * GW + 4) * 4;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_kernel<C>),

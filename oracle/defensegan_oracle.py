@@ -147,6 +147,7 @@ def generator_forward(p: Dict[str, np.ndarray], z: np.ndarray, arch: str = "mnis
     if use_bn:
         a, cache["bn1"] = batchnorm_fwd(a, p["Generator.BN1.scale"].astype(dt),
                                         p["Generator.BN1.offset"].astype(dt), (0,))
+    pre = [a]                                     # pre-activations (tests use them to spot ReLU kinks)
     h = np.maximum(a, 0)
     cin0 = W.shape[1] // 16
     h = h.reshape(-1, 4, 4, cin0)                 # feature f = (oh*4+ow)*C + c   (NHWC reshape)
@@ -163,6 +164,7 @@ def generator_forward(p: Dict[str, np.ndarray], z: np.ndarray, arch: str = "mnis
                                                    p[bn + ".offset"].astype(dt), (0, 1, 2))
         else:
             a = deconv2d(x_in, F, b, h_used)       # crop-aware: cropped outputs never influence anything
+        pre.append(a[:, :h_used, :h_used, :])
         if act == "relu":
             hh = np.maximum(a, 0)[:, :h_used, :h_used, :]
         elif act == "none":
@@ -175,6 +177,7 @@ def generator_forward(p: Dict[str, np.ndarray], z: np.ndarray, arch: str = "mnis
             raise ValueError(act)
         acts.append(hh)
     cache["acts"] = acts
+    cache["pre"] = pre
     return acts[-1], cache
 
 

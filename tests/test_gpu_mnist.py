@@ -54,9 +54,18 @@ def test_loss_and_gradient_vs_oracle(B, R):
     xt = np.repeat(x.astype(np.float64), R, axis=0)
     lo = ((yo - xt) ** 2).reshape(B * R, -1).mean(axis=1)
     go = O.generator_backward(p, cache, 2.0 / 784 * (yo - xt), "mnist")
-    np.testing.assert_allclose(y, yo, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(y, yo, rtol=0, atol=5e-6)        # fp32 vs fp64 at gain 3.0 (|pre-activation| up to ~6)
     np.testing.assert_allclose(loss, lo, rtol=1e-5)
-    assert _rel(dz, go) < 1e-5, _rel(dz, go)
+    # ReluGrad is discontinuous: a row whose pre-activation sits within fp32 rounding of a kink may take the
+    # other branch than the float64 oracle.  Such rows are excluded from the strict gate (and bounded loosely).
+    kink = np.zeros(B * R, bool)
+    for a_pre in cache["pre"][:-1]:
+        kink |= (np.abs(a_pre).reshape(B * R, -1).min(axis=1) < 2e-6)
+    assert kink.mean() < 0.1
+    scale = np.abs(go).max()
+    err = np.abs(dz - go).max(axis=1) / scale
+    assert (err[~kink] < 1e-5).all(), err[~kink].max()
+    assert (err < 0.2).all(), err.max()
 
 
 @pytest.mark.parametrize("name", ["mnist_clean_L5", "mnist_adv_L3", "fmnist_clean_L4"])
