@@ -89,6 +89,15 @@ struct dg_handle {
     GemmOp F1, B1;
     std::vector<GemmOp> Fd, Bd;   // per non-final deconv
     int nsplit = 8;
+    int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
+    int lds_pad = 0;
+    int two_streams = 1;
+    int two_stream_min_rows = 1024;
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int clk_probe = 0;
+    std::string clk_probe_op;
+    long long* d_clk = nullptr;
     std::map<std::string, int> tile_override;
 
     // workspace
@@ -269,26 +278,42 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     const int bm = dg::gemm_tile_bm(op.tile);
     a.n_mtiles = (n_rows + bm - 1) / bm;
     a.mode = op.mode;
+    a.n_pos = (int)op.plan.pos.size();
+    a.xcd_map = h->xcd_map;
+    a.lds_pad = h->lds_pad;
+    a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
     ProfScope ps(h, s, prof, op.name, 2.0 * (double)op.plan.macs_per_row * n_rows);
     dg::launch_gemm(op.tile, a, (int)op.plan.pos.size(), s);
 }
 
+// A row group = a contiguous range of latent rows (whole images) processed on one stream.  Rows are independent
+// (use_bn = False), so a batch may be split into groups that run concurrently on two streams: one group's
+// VALU/LDS-bound tail and short kernels then overlap the other group's MFMA-bound GEMMs.
+struct RowGroup {
+    int row0 = 0, n_rows = 0;
+    hipStream_t s = nullptr;
+};
+
 // forward chain at the current h->z; fills activations, loss, (y when want_y); when do_backward the tail also
-// leaves the gradient w.r.t. the last GEMM activation in place.
-void run_forward(dg_handle* h, const float* x, int n_rows, int R, bool want_y, bool tail_backward, hipStream_t s,
-                 bool prof) {
-    run_gemm(h, h->F1, h->z, h->act[0], n_rows, s, prof);
+// leaves the gradient w.r.t. the last GEMM activation in place.  x points at image 0 of the CALL (row0 / R
+// images are skipped inside).
+void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool tail_backward, bool prof) {
+    const int n_rows = g.n_rows;
+    hipStream_t s = g.s;
+    const int64_t r0 = g.row0;
+    run_gemm(h, h->F1, h->z + r0 * h->latent, h->act[0] + r0 * h->act_row[0], n_rows, s, prof);
     const int nd = (int)h->dec.size();
-    for (int d = 0; d + 1 < nd; ++d) run_gemm(h, h->Fd[d], h->act[d], h->act[d + 1], n_rows, s, prof);
+    for (int d = 0; d + 1 < nd; ++d)
+        run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], h->act[d + 1] + r0 * h->act_row[d + 1], n_rows, s, prof);
     const DeconvSpec& last = h->dec[nd - 1];
     if (h->arch == DG_ARCH_MNIST28) {
         dg::MnistTailArgs t;
-        t.h3 = h->act[nd - 1];
+        t.h3 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
         t.F5 = h->F[nd - 1];
         t.b5 = h->bias[nd - 1];
-        t.x = x;
-        t.loss = h->loss;
-        t.y = want_y ? h->y : nullptr;
+        t.x = x + (r0 / R) * h->P;
+        t.loss = h->loss + r0;
+        t.y = want_y ? h->y + r0 * h->P : nullptr;
         t.n_rows = n_rows;
         t.R = R;
         t.C = last.cin;
@@ -299,10 +324,12 @@ void run_forward(dg_handle* h, const float* x, int n_rows, int R, bool want_y, b
     }
 }
 
-void run_backward(dg_handle* h, int n_rows, hipStream_t s, bool prof) {
+void run_backward(dg_handle* h, const RowGroup& g, bool prof) {
     const int nd = (int)h->dec.size();
-    for (int d = nd - 2; d >= 0; --d) run_gemm(h, h->Bd[d], h->act[d + 1], h->act[d], n_rows, s, prof);
-    run_gemm(h, h->B1, h->act[0], h->part, n_rows, s, prof);
+    const int64_t r0 = g.row0;
+    for (int d = nd - 2; d >= 0; --d)
+        run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof);
+    run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
 
 int check_ready(dg_handle* h) {
@@ -383,6 +410,12 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     }
     if (e == hipSuccess) e = hipMemset(h->xzero, 0, (size_t)h->P * sizeof(float));
     if (e != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(weights): %s", hipGetErrorString(e)); }
+    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+        dg_destroy(h);
+        return fail(DG_E_HIP, "cannot create the side stream / events");
+    }
     int rc = build_plans(h);
     if (rc) { dg_destroy(h); return rc; }
     h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
@@ -402,6 +435,10 @@ int dg_destroy(dg_handle* h) {
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero);
+    if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
+    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto& p : h->F) fr(p);
     for (auto& p : h->Ft) fr(p);
     for (auto& p : h->bias) fr(p);
@@ -509,16 +546,35 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
     const int steps = L > 1 ? L : 1;
+    // split the batch (by image) into two row groups on two streams when it is large enough to fill the chip twice
+    RowGroup grp[2];
+    int ngroups = 1;
+    grp[0].row0 = 0; grp[0].n_rows = n_rows; grp[0].s = s;
+    if (h->two_streams && B >= 2 && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
+        const int b0 = (B + 1) / 2;
+        grp[0].n_rows = b0 * R;
+        grp[1].row0 = b0 * R; grp[1].n_rows = n_rows - b0 * R; grp[1].s = h->side_stream;
+        ngroups = 2;
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+    }
     for (int k = 0; k < steps; ++k) {
         const bool last = (k == steps - 1);
         const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
-        run_forward(h, x, n_rows, R, /*want_y=*/last, /*tail_backward=*/!last, s, prof);
-        if (last) break;
-        run_backward(h, n_rows, s, prof);
-        {
-            ProfScope ps(h, s, prof, "UPD", 0.0);
-            dg::launch_momentum_update(h->z, h->m, h->part, h->nsplit, n_rows, h->latent, lr, momentum, nullptr, s);
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const RowGroup& g = grp[gi];
+            run_forward(h, x, g, R, /*want_y=*/last, /*tail_backward=*/!last, prof);
+            if (last) continue;
+            run_backward(h, g, prof);
+            ProfScope ps(h, g.s, prof, "UPD", 0.0);
+            const int64_t r0 = g.row0;
+            dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
+                                       h->nsplit, g.n_rows, h->latent, lr, momentum, nullptr, g.s);
         }
+    }
+    if (ngroups == 2) {
+        HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
     }
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -537,7 +593,8 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)N * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     // the loss is discarded here: every row is compared with one all-zero image (R = N -> image 0)
-    run_forward(h, h->xzero, N, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, s, false);
+    RowGroup g; g.n_rows = N; g.s = s;
+    run_forward(h, h->xzero, g, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, false);
     HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)N * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return DG_OK;
@@ -554,11 +611,12 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     rc = ensure_workspace(h, n_rows);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
-    run_forward(h, x, n_rows, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, s, false);
+    RowGroup g; g.n_rows = n_rows; g.s = s;
+    run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, false);
     if (out_y) HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)n_rows * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_dz) {
-        run_backward(h, n_rows, s, false);
+        run_backward(h, g, false);
         dg::launch_momentum_update(nullptr, nullptr, h->part, h->nsplit, n_rows, h->latent, 0.f, 0.f, out_dz, s);
     }
     HIP_TRY(hipGetLastError());
@@ -604,6 +662,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
+    else if (w == "clk" && h->d_clk) { src = reinterpret_cast<const float*>(h->d_clk); avail = 4; }
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
         if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
@@ -632,6 +691,30 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
             h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
             h->Bd[d].W = h->Ft[d];
         }
+        return DG_OK;
+    }
+    if (k == "clk_probe") {      // value = op name ("F3"); read back with dg_debug_read("clk")
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_clk) HIP_TRY(hipMalloc(&h->d_clk, 2 * sizeof(long long)));
+        HIP_TRY(hipMemset(h->d_clk, 0, 2 * sizeof(long long)));
+        h->clk_probe_op = value;
+        h->clk_probe = h->clk_probe_op.empty() ? 0 : 1;
+        return DG_OK;
+    }
+    if (k == "two_streams") {
+        h->two_streams = atoi(value) ? 1 : 0;
+        return DG_OK;
+    }
+    if (k == "two_stream_min_rows") {
+        h->two_stream_min_rows = atoi(value);
+        return DG_OK;
+    }
+    if (k == "lds_pad") {
+        h->lds_pad = atoi(value);
+        return DG_OK;
+    }
+    if (k == "xcd_map") {
+        h->xcd_map = atoi(value) ? 1 : 0;
         return DG_OK;
     }
     if (k == "nsplit") {

@@ -40,9 +40,26 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    // measurement hook: shader-clock and 100 MHz real-time stamps of workgroup 0 (effective clock under load)
+    long long clk0 = 0, rt0 = 0;
+    if (g.clk && blockIdx.x == 0) { clk0 = clock64(); rt0 = wall_clock64(); }
 
-    const int pn = blockIdx.x / g.n_mtiles;
-    const int mt = blockIdx.x - pn * g.n_mtiles;
+    // Block -> (M tile, position) map.  xcd_map: workgroups are observed to land on XCD blockIdx % 8 (speed
+    // only, never correctness): XCD x walks M tiles x, x+8, ... and, for each, every output position
+    // (longest K first), so one M tile's input rows (1-3 MB) and the layer's filters stay in that XCD's 4 MB L2
+    // while all positions that re-read them are processed.
+    int pn, mt;
+    if (g.xcd_map) {
+        const int xcd = blockIdx.x & 7;
+        const int local = blockIdx.x >> 3;
+        const int mg = local / g.n_pos;
+        pn = local - mg * g.n_pos;
+        mt = mg * 8 + xcd;
+        if (mt >= g.n_mtiles) return;
+    } else {
+        pn = blockIdx.x / g.n_mtiles;
+        mt = blockIdx.x - pn * g.n_mtiles;
+    }
     const PosEntry pe = g.pos[pn];
     const int pe_out_off = __builtin_amdgcn_readfirstlane(pe.out_off);
     const int pe_n0 = __builtin_amdgcn_readfirstlane(pe.n0);
@@ -80,23 +97,36 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
     const int nchunks = pe_tap_count * chunks_per_tap;
     const TapEntry* taps = g.taps + pe_tap_begin;
 
+    // Staging plan.  Slot s < SA stages 8 A rows per wave, slot s >= SA stages 8 filter rows; the slots of chunk
+    // c+1 are issued BETWEEN the MFMA groups of chunk c (slot s rides with k-step s % 4) instead of in one burst
+    // behind the barrier, where they would delay the first fragment reads of the chunk (measured: +12 % MFMA
+    // rate, tools/ubench/stage_cost4.hip).  The tap record of the NEXT tap is fetched one tap early (plain load).
+    constexpr int NS = SA + SB;
     int ld_tap = 0, ld_k = 0;
-    auto issue = [&](int stage) {
-        const TapEntry te = taps[ld_tap];
-        const int aoff = __builtin_amdgcn_readfirstlane(te.a_off) + ld_k;
-        const int woff = __builtin_amdgcn_readfirstlane(te.w_off) + ld_k;
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sB = sA + BM * ROW_BYTES;
-#pragma unroll
-        for (int s = 0; s < SA; ++s)
-            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(asrc[s] + aoff),
-                                             DG_LDS_PTR(sA + (s * 4 + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int s = 0; s < SB; ++s)
-            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(wsrc[s] + woff),
-                                             DG_LDS_PTR(sB + (s * 4 + wave) * 1024), 16, 0, 0);
+    TapEntry te_nxt = taps[pe_tap_count > 1 ? 1 : 0];
+    int cur_a = __builtin_amdgcn_readfirstlane(taps[0].a_off);
+    int cur_w = __builtin_amdgcn_readfirstlane(taps[0].w_off);
+    int aoff = 0, woff = 0;                    // operand offsets of the chunk being staged
+    auto next_chunk_offsets = [&]() {
+        aoff = cur_a + ld_k;
+        woff = cur_w + ld_k;
         ld_k += BK;
-        if (ld_k == g.kch) { ld_k = 0; ++ld_tap; }
+        if (ld_k == g.kch) {
+            ld_k = 0;
+            ++ld_tap;
+            cur_a = __builtin_amdgcn_readfirstlane(te_nxt.a_off);
+            cur_w = __builtin_amdgcn_readfirstlane(te_nxt.w_off);
+            const int nx = ld_tap + 1 < pe_tap_count ? ld_tap + 1 : pe_tap_count - 1;
+            te_nxt = taps[nx];
+        }
+    };
+    auto issue_slot = [&](int s, char* stage_base) {
+        if (s < SA)
+            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(asrc[s < SA ? s : 0] + aoff),
+                                             DG_LDS_PTR(stage_base + (s * 4 + wave) * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(wsrc[s >= SA ? s - SA : 0] + woff),
+                                             DG_LDS_PTR(stage_base + BM * ROW_BYTES + ((s - SA) * 4 + wave) * 1024), 16, 0, 0);
     };
 
     // fragment read addresses (byte offsets inside a stage), fixed per thread
@@ -116,32 +146,59 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         b_sw[j] = swz(r);
     }
 
-    issue(0);
+    next_chunk_offsets();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) issue_slot(s, smem);
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // chunk c landed for every wave; stage (c+1)&1 is free
-        if (c + 1 < nchunks) issue((c + 1) & 1);
+        const bool more = c + 1 < nchunks;
+        if (more) next_chunk_offsets();
         const char* st = smem + (c & 1) * STAGE_BYTES;
+        char* nx = smem + ((c + 1) & 1) * STAGE_BYTES;
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((fh ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((fh ^ b_sw[j]) << 4));
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f32x4 a[TM], b[TN];
-            const int chunk = kk * 2 + fh;
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk < 3) {                          // fragments of k-step kk+1 while kk computes
+                const int chunk = (kk + 1) * 2 + fh;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((chunk ^ a_sw[i]) << 4));
+                for (int i = 0; i < TM; ++i)
+                    a[nxt][i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((chunk ^ a_sw[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((chunk ^ b_sw[j]) << 4));
+                for (int j = 0; j < TN; ++j)
+                    b[nxt][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((chunk ^ b_sw[j]) << 4));
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if ((s & 3) == kk) issue_slot(s, nx);
+            }
+#pragma unroll
+            for (int e = 2; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
         }
     }
 
+    if (g.clk && blockIdx.x == 0 && tid == 0) {
+        g.clk[0] = clock64() - clk0;
+        g.clk[1] = wall_clock64() - rt0;
+    }
     // ---- epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
     // Each store instruction writes two 128-B row segments (32 consecutive channels x 2 rows).
 #pragma unroll
@@ -175,14 +232,15 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 
 template <int BM, int BN, int MODE>
 static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
-    constexpr int lds = 2 * (BM + BN) * ROW_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    const int lds = 2 * (BM + BN) * ROW_BYTES + (a.lds_pad > 0 ? a.lds_pad : 0);
+    static int attr_lds = 0;
+    if (attr_lds < lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
+        attr_lds = lds;
     }
-    const unsigned grid = (unsigned)n_pos * (unsigned)a.n_mtiles;
+    const unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
+                                    : (unsigned)n_pos * (unsigned)a.n_mtiles;
     hipLaunchKernelGGL((gemm_gather_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, s, a);
 }
 

@@ -35,6 +35,10 @@ struct GemmArgs {
     int n_rows;
     int n_mtiles;
     int mode;
+    int n_pos;           // number of PosEntry records
+    int xcd_map;         // 1: XCD-aware block order (see dg_gemm.hip)
+    int lds_pad;         // extra dynamic LDS bytes (occupancy experiments)
+    long long* clk;      // optional [2]: shader-clock ticks, 100 MHz ticks spent by workgroup 0
 };
 
 // tile shapes: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64  (BM x BN)

@@ -60,8 +60,8 @@ def test_loss_and_gradient_vs_oracle(B, R):
     # other branch than the float64 oracle.  Such rows are excluded from the strict gate (and bounded loosely).
     kink = np.zeros(B * R, bool)
     for a_pre in cache["pre"][:-1]:
-        kink |= (np.abs(a_pre).reshape(B * R, -1).min(axis=1) < 2e-6)
-    assert kink.mean() < 0.1
+        kink |= (np.abs(a_pre).reshape(B * R, -1).min(axis=1) < 1e-6)
+    assert kink.sum() <= max(2, 0.25 * B * R)
     scale = np.abs(go).max()
     err = np.abs(dz - go).max(axis=1) / scale
     assert (err[~kink] < 1e-5).all(), err[~kink].max()
