@@ -46,6 +46,25 @@ struct DeconvSpec {
     const char* name;   // reference layer name
     int cin, cout, h_in, e_used;
     int act;            // 0 relu, 1 none, 2 final (sigmoid / tanh in the tail)
+    const char* bn;     // BN layer applied to this layer's output when use_bn ("" = none)
+};
+
+// One activation buffer: act[0] = Linear output [N, 16 positions, 4*net_dim]; act[d+1] = output of deconv d.
+struct ActInfo {
+    int pitch = 0;          // stored positions per spatial dimension
+    int valid = 0;          // leading positions that are consumed downstream (7 of 8 after the MNIST crop)
+    int C = 0;              // channels
+    int64_t row_floats = 0; // floats per latent row
+    bool has_bn = false;
+    std::string bn_name;
+    int bn_C = 0;           // BN columns (4096 features for BN1, channels otherwise)
+    int64_t bn_rows = 0;    // BN rows per latent row (1 for BN1, pitch^2 otherwise)
+    float* buf = nullptr;
+    float* xhat = nullptr;
+    float* scale = nullptr;   // [bn_C]
+    float* offset = nullptr;  // [bn_C]
+    float* fstats = nullptr;  // [2, bn_C]
+    float* bstats = nullptr;  // [2, bn_C]
 };
 
 struct GemmOp {
@@ -104,8 +123,12 @@ struct dg_handle {
     int64_t cap_rows = 0;
     float *z = nullptr, *m = nullptr, *part = nullptr, *loss = nullptr, *y = nullptr;
     float* xzero = nullptr;        // [P] zeros: stand-in target for dg_generate
+    std::vector<ActInfo> ai;       // per activation buffer (sizes, BN parameters)
     std::vector<float*> act;       // act[0] = h1 [N, lin_out]; act[d+1] = output of deconv d (non-final)
     std::vector<int64_t> act_row;  // floats per latent row
+    double* bn_part = nullptr;     // BN partial sums scratch
+    float* g6 = nullptr;           // CelebA: da6 [N, 64*64*3]
+    float* loss_part = nullptr;    // CelebA: [N, 8]
 
     // profiling
     int prof_stride = 0;
@@ -177,6 +200,28 @@ int default_tile(const std::string& name, int ncols) {
     return 1;                         // 64x128
 }
 
+// Fills h->ai (geometry of every activation buffer) from the architecture and use_bn.
+void describe_activations(dg_handle* h) {
+    const int nd = (int)h->dec.size();
+    h->ai.assign(nd, ActInfo());
+    ActInfo& a0 = h->ai[0];
+    a0.pitch = 4; a0.valid = 4; a0.C = h->lin_out / 16; a0.row_floats = h->lin_out;
+    a0.has_bn = h->use_bn != 0; a0.bn_name = "Generator.BN1"; a0.bn_C = h->lin_out; a0.bn_rows = 1;
+    for (int d = 0; d + 1 < nd; ++d) {
+        const DeconvSpec& s = h->dec[d];
+        ActInfo& a = h->ai[d + 1];
+        a.has_bn = h->use_bn && s.bn[0] != 0;
+        a.valid = s.e_used;
+        // BN statistics cover the full 2h x 2h map; the MNIST crop comes after the ReLU (dataset_models.py:52-59)
+        a.pitch = a.has_bn ? 2 * s.h_in : s.e_used;
+        a.C = s.cout;
+        a.row_floats = (int64_t)a.pitch * a.pitch * a.C;
+        a.bn_name = s.bn;
+        a.bn_C = s.cout;
+        a.bn_rows = (int64_t)a.pitch * a.pitch;
+    }
+}
+
 int build_plans(dg_handle* h) {
     auto tile_for = [&](const std::string& name, int ncols) {
         auto it = h->tile_override.find(name);
@@ -184,6 +229,7 @@ int build_plans(dg_handle* h) {
         if (ncols % dg::gemm_tile_bn(t) != 0) t = (t & 1) ? 3 : 2;   // fall back to 64 columns
         return t;
     };
+    describe_activations(h);
     {
         GemmOp& op = h->F1;
         op.name = "F1";
@@ -212,14 +258,16 @@ int build_plans(dg_handle* h) {
     h->Bd.assign(nd - 1, GemmOp());
     for (int d = 0; d + 1 < nd; ++d) {
         const DeconvSpec& s = h->dec[d];
-        const int e = s.e_used;          // positions computed and stored (row pitch = e)
-        const int in_pitch = d == 0 ? 4 : h->dec[d - 1].e_used;
+        const ActInfo& in = h->ai[d];
+        const ActInfo& out = h->ai[d + 1];
         {
             GemmOp& op = h->Fd[d];
             op.name = std::string("F") + s.name[10];     // "Generator.N" -> "FN"
             op.tile = tile_for(op.name, s.cout);
-            op.plan = dg::plan_deconv_fwd(s.h_in, in_pitch, e, e, s.cin, s.cout, dg::gemm_tile_bn(op.tile));
-            op.mode = s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS;
+            // with BN every stored position is computed (statistics need the cropped row/column too)
+            op.plan = dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin, s.cout,
+                                          dg::gemm_tile_bn(op.tile));
+            op.mode = out.has_bn ? dg::EPI_BIAS : (s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS);
             int rc = upload_plan(op);
             if (rc) return rc;
         }
@@ -227,7 +275,10 @@ int build_plans(dg_handle* h) {
             GemmOp& op = h->Bd[d];
             op.name = std::string("B") + s.name[10];
             op.tile = tile_for(op.name, s.cin);
-            op.plan = dg::plan_deconv_bwd(s.h_in, in_pitch, e, e, s.cin, s.cout, dg::gemm_tile_bn(op.tile));
+            // the incoming gradient is non-zero on the whole stored map after a BN backward, else only on the used block
+            op.plan = dg::plan_deconv_bwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin, s.cout,
+                                          dg::gemm_tile_bn(op.tile));
+            if (in.pitch > in.valid) dg::plan_add_zero_positions(op.plan, in.valid, in.pitch, s.cin);
             op.mode = dg::EPI_MASK;      // every backward output lands on a ReLU activation (h1, h2, h3)
             int rc = upload_plan(op);
             if (rc) return rc;
@@ -238,13 +289,16 @@ int build_plans(dg_handle* h) {
 
 void free_workspace(dg_handle* h) {
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y);
+    fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y); fr(h->g6); fr(h->loss_part);
     for (auto& a : h->act) fr(a);
+    for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); }
+    if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
     h->cap_rows = 0;
 }
 
 int ensure_workspace(dg_handle* h, int64_t rows) {
     if (rows <= h->cap_rows) return DG_OK;
+    HIP_TRY(hipDeviceSynchronize());
     free_workspace(h);
     const int64_t cap = rows;
     HIP_TRY(hipMalloc(&h->z, cap * h->latent * sizeof(float)));
@@ -252,12 +306,26 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     HIP_TRY(hipMalloc(&h->part, cap * h->nsplit * h->latent * sizeof(float)));
     HIP_TRY(hipMalloc(&h->loss, cap * sizeof(float)));
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
+    if (h->arch == DG_ARCH_CELEBA64) {
+        HIP_TRY(hipMalloc(&h->g6, cap * h->P * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->loss_part, cap * 8 * sizeof(float)));
+    }
     const int nd = (int)h->dec.size();
     h->act.assign(nd, nullptr);
     h->act_row.assign(nd, 0);
-    h->act_row[0] = h->lin_out;
-    for (int d = 0; d + 1 < nd; ++d) h->act_row[d + 1] = (int64_t)h->dec[d].e_used * h->dec[d].e_used * h->dec[d].cout;
-    for (int d = 0; d < nd; ++d) HIP_TRY(hipMalloc(&h->act[d], cap * h->act_row[d] * sizeof(float)));
+    size_t part_doubles = 0;
+    for (int d = 0; d < nd; ++d) {
+        ActInfo& a = h->ai[d];
+        h->act_row[d] = a.row_floats;
+        HIP_TRY(hipMalloc(&h->act[d], cap * a.row_floats * sizeof(float)));
+        a.buf = h->act[d];
+        if (a.has_bn) {
+            HIP_TRY(hipMalloc(&a.xhat, cap * a.row_floats * sizeof(float)));
+            const size_t need = (size_t)dg::bn_num_blocks(cap * a.bn_rows) * 2 * a.bn_C;
+            if (need > part_doubles) part_doubles = need;
+        }
+    }
+    if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
     h->cap_rows = cap;
     return DG_OK;
 }
@@ -294,17 +362,40 @@ struct RowGroup {
     hipStream_t s = nullptr;
 };
 
-// forward chain at the current h->z; fills activations, loss, (y when want_y); when do_backward the tail also
+dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
+    dg::BnArgs b;
+    b.a = a.buf;
+    b.xhat = a.xhat;
+    b.part = h->bn_part;
+    b.fstats = a.fstats;
+    b.bstats = a.bstats;
+    b.scale = a.scale;
+    b.offset = a.offset;
+    b.rows = (int64_t)n_rows * a.bn_rows;
+    b.C = a.bn_C;
+    return b;
+}
+
+// forward chain at the current h->z; fills activations, loss, (y when want_y); when tail_backward the tail also
 // leaves the gradient w.r.t. the last GEMM activation in place.  x points at image 0 of the CALL (row0 / R
-// images are skipped inside).
+// images are skipped inside).  With use_bn the whole call is one row group (batch statistics couple all rows).
 void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool tail_backward, bool prof) {
     const int n_rows = g.n_rows;
     hipStream_t s = g.s;
     const int64_t r0 = g.row0;
     run_gemm(h, h->F1, h->z + r0 * h->latent, h->act[0] + r0 * h->act_row[0], n_rows, s, prof);
+    if (h->ai[0].has_bn) {
+        ProfScope ps(h, s, prof, "BNf", 0.0);
+        dg::launch_bn_forward(bn_args(h, h->ai[0], n_rows), 1, s);
+    }
     const int nd = (int)h->dec.size();
-    for (int d = 0; d + 1 < nd; ++d)
+    for (int d = 0; d + 1 < nd; ++d) {
         run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], h->act[d + 1] + r0 * h->act_row[d + 1], n_rows, s, prof);
+        if (h->ai[d + 1].has_bn) {
+            ProfScope ps(h, s, prof, "BNf", 0.0);
+            dg::launch_bn_forward(bn_args(h, h->ai[d + 1], n_rows), 1, s);
+        }
+    }
     const DeconvSpec& last = h->dec[nd - 1];
     if (h->arch == DG_ARCH_MNIST28) {
         dg::MnistTailArgs t;
@@ -321,14 +412,46 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         ProfScope ps(h, s, prof, tail_backward ? "T5fb" : "T5f", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         dg::launch_mnist_tail(t, s);
+    } else {
+        dg::CelebaTailArgs t;
+        t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
+        t.F6 = h->F[nd - 1];
+        t.b6 = h->bias[nd - 1];
+        t.x = x + (r0 / R) * h->P;
+        t.loss_part = h->loss_part + r0 * 8;
+        t.y = want_y ? h->y + r0 * h->P : nullptr;
+        t.g6 = h->g6 + r0 * h->P;
+        t.n_rows = n_rows;
+        t.R = R;
+        t.C = last.cin;
+        t.do_backward = tail_backward ? 1 : 0;
+        const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
+        {
+            ProfScope ps(h, s, prof, "T6f", 2.0 * macs * n_rows);
+            dg::launch_celeba_tail_fwd(t, s);
+        }
+        dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
+        if (tail_backward) {
+            ProfScope ps(h, s, prof, "T6b", 2.0 * macs * n_rows);
+            dg::launch_celeba_tail_bwd(t, s);
+        }
     }
 }
 
 void run_backward(dg_handle* h, const RowGroup& g, bool prof) {
     const int nd = (int)h->dec.size();
     const int64_t r0 = g.row0;
-    for (int d = nd - 2; d >= 0; --d)
+    for (int d = nd - 2; d >= 0; --d) {
+        if (h->ai[d + 1].has_bn) {
+            ProfScope ps(h, g.s, prof, "BNb", 0.0);
+            dg::launch_bn_backward(bn_args(h, h->ai[d + 1], g.n_rows), g.s);
+        }
         run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof);
+    }
+    if (h->ai[0].has_bn) {
+        ProfScope ps(h, g.s, prof, "BNb", 0.0);
+        dg::launch_bn_backward(bn_args(h, h->ai[0], g.n_rows), g.s);
+    }
     run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
 
@@ -369,8 +492,6 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     if (arch != DG_ARCH_MNIST28 && arch != DG_ARCH_CELEBA64) return fail(DG_E_INVALID, "unknown arch %d", arch);
     if (latent_dim <= 0 || latent_dim % 64) return fail(DG_E_INVALID, "latent_dim must be a positive multiple of 64 (got %d)", latent_dim);
     if (net_dim <= 0 || net_dim % 64 || net_dim > 128) return fail(DG_E_INVALID, "net_dim must be 64 or 128 (got %d)", net_dim);
-    if (use_bn) return fail(DG_E_INVALID, "use_bn=True is not built yet in this round");
-    if (arch == DG_ARCH_CELEBA64) return fail(DG_E_INVALID, "celeba64 is not built yet in this round");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(DG_E_INVALID, "device %d out of range (%d visible)", device, ndev);
@@ -385,12 +506,12 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     const int nd = net_dim;
     if (arch == DG_ARCH_MNIST28) {
         h->img_h = 28; h->img_c = 1;
-        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 7, 0}, {"Generator.3", 2 * nd, nd, 7, 14, 0},
-                  {"Generator.5", nd, 1, 14, 28, 2}};
+        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 7, 0, "Generator.BN2"}, {"Generator.3", 2 * nd, nd, 7, 14, 0, "Generator.BN3"},
+                  {"Generator.5", nd, 1, 14, 28, 2, ""}};
     } else {
         h->img_h = 64; h->img_c = 3;
-        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 8, 0}, {"Generator.3", 2 * nd, nd, 8, 16, 0},
-                  {"Generator.5", nd, nd, 16, 32, 1}, {"Generator.6", nd, 3, 32, 64, 2}};
+        h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 8, 0, "Generator.BN2"}, {"Generator.3", 2 * nd, nd, 8, 16, 0, "Generator.BN3"},
+                  {"Generator.5", nd, nd, 16, 32, 1, ""}, {"Generator.6", nd, 3, 32, 64, 2, ""}};
     }
     h->P = h->img_h * h->img_h * h->img_c;
     const size_t ndec = h->dec.size();
@@ -418,6 +539,13 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     }
     int rc = build_plans(h);
     if (rc) { dg_destroy(h); return rc; }
+    for (auto& a : h->ai) {
+        if (!a.has_bn) continue;
+        hipError_t e2 = hipSuccess;
+        for (float** pp : {&a.scale, &a.offset}) if (e2 == hipSuccess) e2 = hipMalloc(pp, (size_t)a.bn_C * sizeof(float));
+        for (float** pp : {&a.fstats, &a.bstats}) if (e2 == hipSuccess) e2 = hipMalloc(pp, (size_t)2 * a.bn_C * sizeof(float));
+        if (e2 != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(BN parameters): %s", hipGetErrorString(e2)); }
+    }
     h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
     h->B1.W = h->lin_w;
     for (size_t d = 0; d + 1 < ndec; ++d) {
@@ -434,6 +562,7 @@ int dg_destroy(dg_handle* h) {
     prof_collect(h);
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
@@ -505,6 +634,18 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
             return DG_OK;
         }
     }
+    for (auto& a : h->ai) {
+        if (!a.has_bn) continue;
+        for (int which = 0; which < 2; ++which) {
+            if (nm != a.bn_name + (which ? ".offset" : ".scale")) continue;
+            // the reference keeps these with the keep_dims shape of the moments ([1,C] / [1,1,1,C]); accept any
+            // shape with bn_C elements
+            if (n != a.bn_C) return fail(DG_E_INVALID, "%s: expected %d values", name, a.bn_C);
+            HIP_TRY(hipMemcpy(which ? a.offset : a.scale, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            h->have[nm] = true;
+            return DG_OK;
+        }
+    }
     return fail(DG_E_INVALID, "unknown weight name '%s'", name);
 }
 
@@ -515,6 +656,8 @@ int dg_weights_complete(dg_handle* h) {
         if (!h->have.count(std::string(s.name) + ".Filters")) return 0;
         if (!h->have.count(std::string(s.name) + ".Biases")) return 0;
     }
+    for (auto& a : h->ai)
+        if (a.has_bn && (!h->have.count(a.bn_name + ".scale") || !h->have.count(a.bn_name + ".offset"))) return 0;
     return 1;
 }
 
@@ -550,7 +693,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     RowGroup grp[2];
     int ngroups = 1;
     grp[0].row0 = 0; grp[0].n_rows = n_rows; grp[0].s = s;
-    if (h->two_streams && B >= 2 && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
+    if (h->two_streams && !h->use_bn && B >= 2 && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
         const int b0 = (B + 1) / 2;
         grp[0].n_rows = b0 * R;
         grp[1].row0 = b0 * R; grp[1].n_rows = n_rows - b0 * R; grp[1].s = h->side_stream;

@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
     // rate, tools/ubench/stage_cost4.hip).  The tap record of the NEXT tap is fetched one tap early (plain load).
     constexpr int NS = SA + SB;
     int ld_tap = 0, ld_k = 0;
-    TapEntry te_nxt = taps[pe_tap_count > 1 ? 1 : 0];
-    int cur_a = __builtin_amdgcn_readfirstlane(taps[0].a_off);
-    int cur_w = __builtin_amdgcn_readfirstlane(taps[0].w_off);
+    TapEntry te_nxt = pe_tap_count > 0 ? taps[pe_tap_count > 1 ? 1 : 0] : TapEntry{0, 0};
+    const TapEntry te0 = pe_tap_count > 0 ? taps[0] : TapEntry{0, 0};
+    int cur_a = __builtin_amdgcn_readfirstlane(te0.a_off);
+    int cur_w = __builtin_amdgcn_readfirstlane(te0.w_off);
     int aoff = 0, woff = 0;                    // operand offsets of the chunk being staged
     auto next_chunk_offsets = [&]() {
         aoff = cur_a + ld_k;
@@ -146,9 +147,11 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         b_sw[j] = swz(r);
     }
 
-    next_chunk_offsets();
+    if (nchunks > 0) {                         // zero-tap positions (BN mode: cropped outputs) just store zeros
+        next_chunk_offsets();
 #pragma unroll
-    for (int s = 0; s < NS; ++s) issue_slot(s, smem);
+        for (int s = 0; s < NS; ++s) issue_slot(s, smem);
+    }
     for (int c = 0; c < nchunks; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // chunk c landed for every wave; stage (c+1)&1 is free

@@ -68,7 +68,7 @@ struct CelebaTailArgs {
     const float* F6;     // [5,5,3,C]
     const float* b6;     // [3]
     const float* x;      // [B,64,64,3]
-    float* loss_part;    // [N, 16] per-band partial sums of squared error
+    float* loss_part;    // [N, 8] per-band partial sums of squared error
     float* y;            // [N,64,64,3] or nullptr
     float* g6;           // [N,64,64,3] scratch for da6 (needed across band borders)
     int n_rows;
@@ -93,18 +93,21 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
 void launch_fill_zero(float* p, int64_t n, hipStream_t s);
 
 // ---- BatchNorm with batch statistics (tflib/ops/batchnorm.py:80-93) ---------------------------
-// a [rows, C] viewed as rows x C (rows = N*positions); per-column mean / biased variance, eps 1e-5.
+// An activation buffer viewed as [rows, C] (rows = latent rows x positions); per-column mean / biased variance,
+// eps 1e-5, statistics reduced in float64.
 struct BnArgs {
-    float* a;            // in: pre-activation; out: relu(bn(a))  (fwd) | in: dh, out: da (bwd)
-    float* xhat;         // [rows, C] normalised activations saved by fwd
-    float* rstd;         // [C]
+    float* a;            // fwd: pre-activation in, [relu](bn(a)) out | bwd: masked dy in, da out (in place)
+    float* xhat;         // [rows, C] normalised activations (written by fwd, read by bwd)
+    double* part;        // [nblk, 2, C] scratch
+    float* fstats;       // [2, C] mean, rstd (written by fwd)
+    float* bstats;       // [2, C] mean(dy), mean(dy*xhat) (written by bwd)
     const float* scale;  // [C]
     const float* offset; // [C]
-    float* stats;        // [2, C] scratch (sum, sumsq) / (sum dy, sum dy*xhat)
     int64_t rows;
     int C;
 };
-void launch_bn_forward(const BnArgs& a, hipStream_t s);      // stats + normalise + ReLU, keeps xhat
-void launch_bn_backward(const BnArgs& a, const float* h_act, hipStream_t s);
+int bn_num_blocks(int64_t rows);
+void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
+void launch_bn_backward(const BnArgs& a, hipStream_t s);
 
 }  // namespace dg

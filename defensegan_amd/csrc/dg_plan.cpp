@@ -106,4 +106,12 @@ LayerPlan plan_deconv_bwd(int h_in, int out_pitch, int e_out, int a_pitch, int c
     return p;
 }
 
+void plan_add_zero_positions(LayerPlan& p, int used, int pitch, int ncols) {
+    for (int i = 0; i < pitch; ++i)
+        for (int j = 0; j < pitch; ++j) {
+            if (i < used && j < used) continue;
+            for (int n0 = 0; n0 < ncols; n0 += p.bn) p.pos.push_back(PosEntry{(i * pitch + j) * ncols, n0, 0, 0});
+        }
+}
+
 }  // namespace dg

@@ -33,5 +33,8 @@ LayerPlan plan_deconv_fwd(int h_in, int in_pitch, int e_out, int out_pitch, int 
 // Deconv backward-to-input: dh[n,oh,ow,ci] = sum da[n,2oh+kh-1,2ow+kw-1,co] * Ft[kh,kw,ci,co];
 // da valid extent e_out (pitch a_pitch), dh grid h_in (pitch out_pitch).
 LayerPlan plan_deconv_bwd(int h_in, int out_pitch, int e_out, int a_pitch, int cin, int cout, int bn);
+// Adds zero-tap entries for the positions of a (pitch x pitch) grid outside the leading (used x used) block:
+// the epilogue then writes zeros there (gradient of the MNIST crop = zero padding, needed by BN statistics).
+void plan_add_zero_positions(LayerPlan& p, int used, int pitch, int ncols);
 
 }  // namespace dg

@@ -19,13 +19,15 @@ def load_golden(name):
     return d
 
 
-def make_gan(arch="mnist", wseed=1234, gain=2.0, bias_range=0.1, rec_rr=10, rec_iters=200, rec_lr=10.0, **kw):
+def make_gan(arch="mnist", wseed=1234, gain=2.0, bias_range=0.1, rec_rr=10, rec_iters=200, rec_lr=10.0,
+             use_bn=False, **kw):
     from defensegan_amd.gan import dataset_gan_dict
     a = archs.make_arch(arch)
     cls = dataset_gan_dict[{"fmnist": "f-mnist"}.get(arch, arch)]
-    gan = cls(cfg={"USE_BN": False, "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim}, test_mode=True,
+    gan = cls(cfg={"USE_BN": bool(use_bn), "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim}, test_mode=True,
               rec_rr=rec_rr, rec_iters=rec_iters, rec_lr=rec_lr, **kw)
-    p = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=bias_range)
+    p = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=bias_range, use_bn=use_bn,
+                           bn_jitter=0.2 if use_bn else 0.0)
     assert gan.set_weights(p) == []
     return gan, p
 

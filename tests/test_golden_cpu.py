@@ -8,7 +8,7 @@ from oracle import defensegan_oracle as O
 from tests.helpers import load_golden
 
 
-@pytest.mark.parametrize("name", ["mnist_clean_L5", "mnist_adv_L3", "fmnist_clean_L4"])
+@pytest.mark.parametrize("name", ["mnist_clean_L5", "mnist_adv_L3", "fmnist_clean_L4", "celeba_clean_L3"])
 def test_oracle_reproduces_golden(name):
     g = load_golden(name)
     p = synth.make_weights(g["arch"], seed=g["wseed"], gain=g["gain"], bias_range=g["bias_range"])
@@ -19,8 +19,8 @@ def test_oracle_reproduces_golden(name):
     assert (o64["idx"] == g["idx"]).all()
     o32 = O.reconstruct(p, g["x"], g["z0"], g["R"], g["L"], lr=g["lr"], momentum=g["momentum"], arch=g["arch"],
                         dtype=np.float32)
-    np.testing.assert_allclose(o32["rec"], g["rec"], rtol=0, atol=2e-5)
-    np.testing.assert_allclose(o32["loss"], g["loss"], rtol=2e-4)
+    np.testing.assert_allclose(o32["rec"], g["rec"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(o32["loss"], g["loss"], rtol=3e-4)
     assert (o32["idx"] == g["idx"]).all()
 
 

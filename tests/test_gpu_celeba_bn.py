@@ -1,0 +1,120 @@
+"""-m gpu: parity of the CelebA generator path and of the use_bn=True variants with the CPU oracle."""
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth
+from tests.helpers import load_golden, make_gan
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import defensegan_oracle as O
+    return O
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _targets(arch, B, seed):
+    a = archs.make_arch(arch)
+    rs = np.random.RandomState(seed)
+    return (rs.rand(B, *a.image_dim) * (a.in_hi - a.in_lo) + a.in_lo).astype(np.float32)
+
+
+@pytest.mark.parametrize("N", [3, 70])
+def test_celeba_generate_layers_vs_oracle(N):
+    O = _oracle()
+    gan, p = make_gan("celeba", bias_range=0.1)
+    rs = np.random.RandomState(N)
+    z = (rs.standard_normal((N, 128)) * 0.3).astype(np.float32)
+    y = gan.generate(z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), "celeba")
+    acts = cache["acts"]
+    for d in range(4):
+        got = gan.debug_read("act%d" % d, acts[d].size).cpu().numpy().reshape(acts[d].shape)
+        assert _rel(got, acts[d]) < 3e-6, (d, _rel(got, acts[d]))
+    assert y.shape == (N, 64, 64, 3)
+    np.testing.assert_allclose(y, yo, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,R", [(2, 2), (5, 3)])
+def test_celeba_loss_and_gradient_vs_oracle(B, R):
+    O = _oracle()
+    gan, p = make_gan("celeba", gain=2.0, bias_range=0.1)
+    x = _targets("celeba", B, 5)
+    rs = np.random.RandomState(B * 10 + R)
+    z = (rs.standard_normal((B * R, 128)) * 0.2).astype(np.float32)
+    y, loss, dz = gan.loss_grad(x, z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), "celeba")
+    xt = np.repeat(x.astype(np.float64), R, axis=0)
+    lo = ((yo - xt) ** 2).reshape(B * R, -1).mean(axis=1)
+    go = O.generator_backward(p, cache, 2.0 / 12288 * (yo - xt), "celeba")
+    np.testing.assert_allclose(y, yo, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(loss, lo, rtol=1e-5)
+    kink = np.zeros(B * R, bool)
+    for a_pre in cache["pre"][:3]:
+        kink |= (np.abs(a_pre).reshape(B * R, -1).min(axis=1) < 1e-6)
+    err = np.abs(dz - go).max(axis=1) / np.abs(go).max()
+    assert (err[~kink] < 2e-5).all(), err[~kink].max()
+    assert (err < 0.2).all()
+
+
+def test_celeba_reconstruct_matches_golden():
+    g = load_golden("celeba_clean_L3")
+    gan, p = make_gan("celeba", wseed=g["wseed"], gain=g["gain"], bias_range=g["bias_range"],
+                      rec_rr=g["R"], rec_iters=g["L"], rec_lr=g["lr"])
+    out = gan.reconstruct(g["x"], z_init_val=g["z0"], return_details=True)
+    np.testing.assert_allclose(out["loss"], g["loss"], rtol=3e-4)
+    np.testing.assert_allclose(out["z"], g["z"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(out["rec"], g["rec"], rtol=0, atol=5e-5)
+    assert (out["idx"] == g["idx"]).all()
+
+
+@pytest.mark.parametrize("arch", ["mnist", "celeba"])
+def test_bn_forward_backward_vs_oracle(arch):
+    """use_bn=True: batch statistics at inference (batchnorm.py:80-93) couple all B*R rows."""
+    O = _oracle()
+    B, R = 6, 3
+    gan, p = make_gan(arch, gain=2.0, bias_range=0.1, use_bn=True)
+    a = archs.make_arch(arch)
+    x = _targets(arch, B, 3)
+    rs = np.random.RandomState(9)
+    z = (rs.standard_normal((B * R, 128)) * 0.3).astype(np.float32)
+    y, loss, dz = gan.loss_grad(x, z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), arch, True)
+    xt = np.repeat(x.astype(np.float64), R, axis=0)
+    lo = ((yo - xt) ** 2).reshape(B * R, -1).mean(axis=1)
+    go = O.generator_backward(p, cache, 2.0 / a.pixels * (yo - xt), arch, True)
+    np.testing.assert_allclose(y, yo, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(loss, lo, rtol=5e-5)
+    # a ReLU kink anywhere perturbs every row through the statistics: compare in aggregate
+    assert _rel(dz, go) < 5e-3, _rel(dz, go)
+    med = np.median(np.abs(dz - go).max(axis=1) / np.abs(go).max())
+    assert med < 5e-5, med
+
+
+def test_bn_reconstruct_short_horizon_vs_oracle():
+    O = _oracle()
+    B, R, L = 4, 2, 3
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.1, use_bn=True, rec_rr=R, rec_iters=L, rec_lr=1.0)
+    x = _targets("mnist", B, 4)
+    z0 = synth.make_z(B * R, 128, seed=8)
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    ref = O.reconstruct(p, x, z0, R, L, lr=1.0, momentum=0.7, arch="mnist", use_bn=True, dtype=np.float64)
+    np.testing.assert_allclose(out["loss"], ref["loss"], rtol=2e-3)
+    np.testing.assert_allclose(out["rec"], ref["rec"], rtol=0, atol=2e-3)
+    assert (out["idx"] == ref["idx"]).all()
+
+
+def test_bn_mnist_crop_positions_are_zeroed():
+    """MNIST + BN keeps the 8x8 map (statistics cover the cropped row/column); the gradient of the crop is zero
+    padding, which the backward writes explicitly."""
+    B, R = 3, 2
+    gan, p = make_gan("mnist", use_bn=True)
+    x = _targets("mnist", B, 1)
+    z = synth.make_z(B * R, 128, seed=2)
+    gan.loss_grad(x, z)
+    act1 = gan.debug_read("act1", B * R * 8 * 8 * 128).cpu().numpy().reshape(B * R, 8, 8, 128)
+    assert np.isfinite(act1).all()
