@@ -133,8 +133,6 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    gan.profile_reset()
-    gan.profile_enable(args.profile_stride)
     t0 = time.perf_counter()
     out = None
     for i in range(args.steps):
@@ -147,12 +145,21 @@ def main():
         dist.all_gather(gathered, msg)
     barrier()
     dt = time.perf_counter() - t0
-    gan.profile_enable(0)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Per-kernel durations for the roofline leg: hipEvents on the launch stream around every kernel of each
+    # k-th GD iteration, in one extra pass of the same workload AFTER the timed region (the timed region runs the
+    # two row groups of a batch on two streams, whose kernels interleave; the event pass runs single-stream).
+    if args.profile_stride > 0 and rank == 0:
+        gan.profile_reset()
+        gan.profile_enable(args.profile_stride)
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize(dev)
+        gan.profile_enable(0)
+    barrier()
     prof = gan.profile_read()
     if rank == 0:
         images = world * B * args.steps
@@ -167,7 +174,7 @@ def main():
             tf = (p["flops"] / p["launches"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
             kernels.append({"name": p["name"], "launches_sampled": p["launches"], "avg_us": round(avg_ms * 1e3, 2),
                             "tflops": round(tf, 2)})
-        dom = max(kernels, key=lambda k: k["avg_us"]) if kernels else None
+        dom = max(kernels, key=lambda k: k["avg_us"]) if kernels else None   # dominant = longest kernel of an iteration
         roofline = {
             "bound": "mfma",
             "kernel": dom["name"] if dom else None,
