@@ -102,6 +102,7 @@ struct dg_handle {
     float* lin_wt = nullptr;   // [lin_out][latent]   K-contiguous operand of the forward
     float* lin_b = nullptr;
     std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
+    float* tail_pack = nullptr;        // last deconv's filters in MFMA fragment order (forward tail GEMM)
     std::map<std::string, bool> have;
 
     // ops
@@ -110,7 +111,9 @@ struct dg_handle {
     int nsplit = 8;
     int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
     int lds_pad = 0;
-    int two_streams = 1;
+    int tail_mfma = 1;
+    int tail_dbg = 0;
+    int two_streams = 0;   // measured +2.8 % only; off keeps per-kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -411,11 +414,12 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.do_backward = tail_backward ? 1 : 0;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         ProfScope ps(h, s, prof, tail_backward ? "T5fb" : "T5f", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
-        dg::launch_mnist_tail(t, s);
+        if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);
     } else {
         dg::CelebaTailArgs t;
         t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
         t.F6 = h->F[nd - 1];
+        t.F6p = h->tail_pack;
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
         t.loss_part = h->loss_part + r0 * 8;
@@ -425,15 +429,16 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.R = R;
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
+        t.dbg = h->tail_dbg;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
             ProfScope ps(h, s, prof, "T6f", 2.0 * macs * n_rows);
-            dg::launch_celeba_tail_fwd(t, s);
+            if (h->tail_mfma) dg::launch_celeba_tail_fwd_mfma(t, s); else dg::launch_celeba_tail_fwd(t, s);
         }
         dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
         if (tail_backward) {
             ProfScope ps(h, s, prof, "T6b", 2.0 * macs * n_rows);
-            dg::launch_celeba_tail_bwd(t, s);
+            if (h->tail_mfma) dg::launch_celeba_tail_bwd_mfma(t, s); else dg::launch_celeba_tail_bwd(t, s);
         }
     }
 }
@@ -563,7 +568,7 @@ int dg_destroy(dg_handle* h) {
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
-    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero);
+    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -624,6 +629,22 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
                         t[((size_t)k * s.cin + ci) * s.cout + co] = host[((size_t)k * s.cout + co) * s.cin + ci];
             HIP_TRY(hipMemcpy(h->F[d], host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->Ft[d], t.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            if (d + 1 == h->dec.size()) {
+                // tail forward GEMM: B fragments of v_mfma_f32_32x32x2_f32 in load order.  kappa = (kh*5+kw)*cout + co is
+                // the row of host[] (layout [25][cout][cin] == [kappa][c]); lane = (kappa & 31) + 32*half holds
+                // c = 8*kk + 4*half + e of kappa tile t.
+                const int nk = 25 * s.cout, nt = (nk + 31) / 32, kkn = s.cin / 8;
+                std::vector<float> pk((size_t)nt * kkn * 64 * 4, 0.f);
+                for (int tt = 0; tt < nt; ++tt)
+                    for (int kk = 0; kk < kkn; ++kk)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int kappa = tt * 32 + (lane & 31), c = kk * 8 + (lane >> 5) * 4 + e;
+                                if (kappa < nk) pk[(((size_t)tt * kkn + kk) * 64 + lane) * 4 + e] = host[(size_t)kappa * s.cin + c];
+                            }
+                if (!h->tail_pack) HIP_TRY(hipMalloc(&h->tail_pack, pk.size() * sizeof(float)));
+                HIP_TRY(hipMemcpy(h->tail_pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             h->have[nm] = true;
             return DG_OK;
         }
@@ -850,6 +871,14 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "two_stream_min_rows") {
         h->two_stream_min_rows = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_dbg") {
+        h->tail_dbg = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_mfma") {
+        h->tail_mfma = atoi(value) ? 1 : 0;
         return DG_OK;
     }
     if (k == "lds_pad") {

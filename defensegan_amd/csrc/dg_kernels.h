@@ -60,12 +60,14 @@ struct MnistTailArgs {
     int C;               // net_dim (64)
     int do_backward;
 };
-void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);
+void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);        // VALU formulation (dg_tail.hip)
+void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // MFMA formulation (dg_tail_mfma.hip)
 
 // ---- CelebA tail: Generator.6 (64 -> 3, 64x64) + tanh + loss + backward to da5 ----------------
 struct CelebaTailArgs {
     float* h5;           // [N,32,32,C] in: Generator.5 output (no nonlinearity); out: da5
     const float* F6;     // [5,5,3,C]
+    const float* F6p;    // forward filter fragments in MFMA fragment order [3][C/8][64][4] (see dg_tail_mfma.hip)
     const float* b6;     // [3]
     const float* x;      // [B,64,64,3]
     float* loss_part;    // [N, 8] per-band partial sums of squared error
@@ -75,9 +77,12 @@ struct CelebaTailArgs {
     int R;
     int C;
     int do_backward;
+    int dbg;             // timing experiments only: 1 = skip the gather phase, 2 = skip the GEMM phase
 };
-void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s);
+void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s);       // VALU formulation
 void launch_celeba_tail_bwd(const CelebaTailArgs& a, hipStream_t s);
+void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // MFMA formulation
+void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s);
 void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s);
 
 // ---- small kernels ----------------------------------------------------------------------------
