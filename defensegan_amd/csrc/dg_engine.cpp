@@ -196,11 +196,16 @@ int upload_plan(GemmOp& op) {
 }
 
 int default_tile(const std::string& name, int ncols) {
-    // tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very
-    // different K (1..9 or 4..25 taps), so 64-row M tiles keep the dispatch balanced at B*R ~ 2560.
-    if (ncols % 128 != 0) return 2;   // 64 output columns: 128x64
-    if (name == "F1") return 0;       // Linear forward: uniform K = latent, 128x128
-    return 1;                         // 64x128
+    // tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very different K
+    // (1..9 or 4..25 taps) and B*R ~ 2560 gives only 20-40 M tiles, so the choice trades steady-state rate
+    // (128x128: 136 TF, 64x128: 126 TF) against dispatch balance; values measured per layer on MI355X at N = 2560
+    // (gpurun_out/t36_probe.log: F1 44.5 -> 37.1 us, F2 331.7 -> 322.9, F3 377.1 -> 364.1, B1 41.3 -> 33.4).
+    if (name == "F1" || name == "B1") return 3;          // K = latent / split-K: short tiles, many of them
+    if (ncols % 128 != 0) return 3;                       // 64 output columns (Generator.3 fwd, Generator.5)
+    // With the interleaved-DMA K loop the smallest tile wins or ties everywhere at these row counts: balance and
+    // occupancy (5 workgroups/CU) outweigh its higher staging traffic (B3 401 -> 367 us, B2 360 -> 336 us, CelebA
+    // F2 at N = 1280: 230 -> 211 us; MNIST F2 ties at 316-317 us for 128x128 / 64x128 / 64x64).
+    return 3;
 }
 
 // Fills h->ai (geometry of every activation buffer) from the architecture and use_bn.
@@ -346,7 +351,11 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     a.w_rowstride = op.plan.w_rowstride;
     a.kch = op.plan.kch;
     a.n_rows = n_rows;
-    const int bm = dg::gemm_tile_bm(op.tile);
+    // 128-row M tiles only pay off when there are enough of them to balance the dispatch (measured: CelebA F2 at
+    // N = 1280 rows runs 254 us with 128x128 tiles vs 240 us with 64x128); same BN, so the plan is unchanged.
+    int tile = op.tile;
+    if (n_rows < 2048 && dg::gemm_tile_bm(tile) == 128) tile += 1;
+    const int bm = dg::gemm_tile_bm(tile);
     a.n_mtiles = (n_rows + bm - 1) / bm;
     a.mode = op.mode;
     a.n_pos = (int)op.plan.pos.size();
@@ -354,7 +363,7 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     a.lds_pad = h->lds_pad;
     a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
     ProfScope ps(h, s, prof, op.name, 2.0 * (double)op.plan.macs_per_row * n_rows);
-    dg::launch_gemm(op.tile, a, (int)op.plan.pos.size(), s);
+    dg::launch_gemm(tile, a, (int)op.plan.pos.size(), s);
 }
 
 // A row group = a contiguous range of latent rows (whole images) processed on one stream.  Rows are independent

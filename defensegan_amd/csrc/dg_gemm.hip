@@ -12,6 +12,8 @@
 // through the per-lane SOURCE address so the ds_read_b128 fragment reads are bank-conflict free.
 // One b128 fragment read feeds four MFMAs: lane half h = lane>>5 holds k = 8*kk + 4*h + e for
 // e = 0..3, the same K permutation on A and B.
+#include <type_traits>
+
 #include "dg_kernels.h"
 
 namespace dg {
@@ -147,16 +149,47 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         b_sw[j] = swz(r);
     }
 
+    // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk (instead of
+    // DMA for a next chunk), so their HBM/L2 latency hides under that chunk's MFMAs.
+    float oldv[TM][TN][16];
+    auto prefetch_mask = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = pe_n0 + wn * (BN / 2) + j * 32 + frow;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+                const float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
+                const unsigned rs = (unsigned)g.out_rowstride;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int dr = (e & 3) + 8 * (e >> 2);
+                    oldv[i][j][e] = (row0 + dr < g.n_rows) ? obase[(unsigned)dr * rs] : 0.f;
+                }
+            }
+        }
+    };
+    if (MODE == EPI_MASK && nchunks == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oldv[i][j][e] = 0.f;
+    }
     if (nchunks > 0) {                         // zero-tap positions (BN mode: cropped outputs) just store zeros
         next_chunk_offsets();
 #pragma unroll
         for (int s = 0; s < NS; ++s) issue_slot(s, smem);
     }
-    for (int c = 0; c < nchunks; ++c) {
+    // One K chunk: wait for its operands, then 4 k-steps of MFMAs with the next chunk's DMA (or, in the LAST chunk of a
+    // ReluGrad tile, the mask prefetch) slotted between the MFMA groups.  The last chunk is peeled so the steady
+    // loop carries no "is there a next chunk" branches.
+    auto chunk_body = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                         // chunk c landed for every wave; stage (c+1)&1 is free
-        const bool more = c + 1 < nchunks;
-        if (more) next_chunk_offsets();
+        if constexpr (!LAST) next_chunk_offsets();
         const char* st = smem + (c & 1) * STAGE_BYTES;
         char* nx = smem + ((c + 1) & 1) * STAGE_BYTES;
         f32x4 a[2][TM], b[2][TN];
@@ -183,10 +216,12 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
-            if (more) {
+            if constexpr (!LAST) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
                     if ((s & 3) == kk) issue_slot(s, nx);
+            } else if constexpr (MODE == EPI_MASK) {
+                if (kk == 0) prefetch_mask();
             }
 #pragma unroll
             for (int e = 2; e < 4; ++e)
@@ -196,7 +231,9 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
         }
-    }
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::false_type());
+    if (nchunks > 0) chunk_body(nchunks - 1, std::true_type());
 
     if (g.clk && blockIdx.x == 0 && tid == 0) {
         g.clk[0] = clock64() - clk0;
@@ -213,20 +250,12 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i) {
             const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
             float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
-            float oldv[16];
-            if constexpr (MODE == EPI_MASK) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dr = (e & 3) + 8 * (e >> 2);
-                    oldv[e] = (row0 + dr < g.n_rows) ? obase[(long long)dr * g.out_rowstride] : 0.f;
-                }
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int dr = (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e] + bv;
                 if constexpr (MODE == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-                if constexpr (MODE == EPI_MASK) v = oldv[e] > 0.f ? v : 0.f;
+                if constexpr (MODE == EPI_MASK) v = oldv[i][j][e] > 0.f ? v : 0.f;
                 if (row0 + dr < g.n_rows) obase[(long long)dr * g.out_rowstride] = v;
             }
         }

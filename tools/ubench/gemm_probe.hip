@@ -44,9 +44,9 @@ int main(int argc, char** argv) {
     CHECK(hipMalloc(&A, abytes)); CHECK(hipMalloc(&Out, abytes)); CHECK(hipMalloc(&W, 8 << 20)); CHECK(hipMalloc(&bias, 1 << 16));
     CHECK(hipMemset(A, 0, abytes)); CHECK(hipMemset(Out, 0, abytes)); CHECK(hipMemset(W, 0, 8 << 20)); CHECK(hipMemset(bias, 0, 1 << 16));
     {   // steady-state check: exactly one resident wave of workgroups (256 CUs x 3), every tile 1504 chunks long
-        for (int tile : {1, 0}) {
+        for (int tile : {3, 2, 1, 0}) {
             const int bn = dg::gemm_tile_bn(tile), bm = dg::gemm_tile_bm(tile);
-            const int wg_per_cu = tile == 1 ? 3 : 2;
+            const int wg_per_cu = tile == 3 ? 5 : (tile == 0 ? 2 : 3);
             dg::LayerPlan p = dg::plan_deconv_fwd(4, 4, 7, 7, 256, 128, bn);
             p.out_rowstride = 128;          // keep the synthetic output inside the buffer
             p.pos.resize(wg_per_cu);
@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
         }
     }
     struct L { const char* name; dg::LayerPlan p; int mode; };
-    for (int tile : {1, 0}) {
+    for (int tile : {3}) {
         const int bn = dg::gemm_tile_bn(tile);
         std::vector<L> layers;
         layers.push_back({"F2", dg::plan_deconv_fwd(4, 4, 7, 7, 256, 128, bn), dg::EPI_BIAS_RELU});
