@@ -64,6 +64,11 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
     torch.set_num_threads(cores)
     per_pass = probe / (2 * Ls - 1)
     Ls = int(max(3, min(L, (budget_s / max(per_pass, 1e-6) + 1) // 2)))
+    if Ls == L:                                   # fast host: spend the budget on more images instead
+        grow = int(min(len(x_np), 64, max(nimg, nimg * budget_s / max(per_pass * (2 * L - 1), 1e-6))))
+        if grow > nimg:
+            nimg = grow
+            z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
     t0 = time.perf_counter()
     T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
     dt = time.perf_counter() - t0
@@ -166,18 +171,31 @@ def main():
         value = images / dt
         flop_img = archs.flop_per_image(a, R, max(L, 1))
         path_tflops = value * flop_img / 1e12 / world           # per GPU
-        kernels = []
+        # profile entries are "<layer>@<kernel symbol>": per-layer rows for the breakdown, per-symbol groups (what
+        # rocprofv3 --stats aggregates) for the roofline of the dominant kernel
+        kernels, groups = [], {}
         for p in prof:
             if p["launches"] == 0:
                 continue
+            layer, _, sym = p["name"].partition("@")
             avg_ms = p["ms"] / p["launches"]
             tf = (p["flops"] / p["launches"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            kernels.append({"name": p["name"], "launches_sampled": p["launches"], "avg_us": round(avg_ms * 1e3, 2),
-                            "tflops": round(tf, 2)})
-        dom = max(kernels, key=lambda k: k["avg_us"]) if kernels else None   # dominant = longest kernel of an iteration
+            kernels.append({"name": layer, "kernel": sym, "launches_sampled": p["launches"],
+                            "avg_us": round(avg_ms * 1e3, 2), "tflops": round(tf, 2)})
+            g = groups.setdefault(sym, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            g["ms"] += p["ms"]; g["flops"] += p["flops"]; g["launches"] += p["launches"]
+        dom = None
+        if groups:
+            sym = max(groups, key=lambda k: groups[k]["ms"])          # dominant kernel = most total time
+            g = groups[sym]
+            dom = {"kernel": sym, "avg_us": round(g["ms"] / g["launches"] * 1e3, 2),
+                   "flop_per_launch": g["flops"] / g["launches"],
+                   "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2)}
         roofline = {
             "bound": "mfma",
-            "kernel": dom["name"] if dom else None,
+            "kernel": dom["kernel"] if dom else None,
+            "avg_launch_us": dom["avg_us"] if dom else None,
+            "flop_per_launch": dom["flop_per_launch"] if dom else None,
             "achieved": dom["tflops"] if dom else round(path_tflops, 2),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round((dom["tflops"] if dom else path_tflops) / PEAK_FP32_TFLOPS, 4),

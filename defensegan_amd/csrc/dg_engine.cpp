@@ -362,7 +362,10 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     a.xcd_map = h->xcd_map;
     a.lds_pad = h->lds_pad;
     a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
-    ProfScope ps(h, s, prof, op.name, 2.0 * (double)op.plan.macs_per_row * n_rows);
+    // profile entries are "<layer>@<kernel symbol>" so that bench.py can group launches the way rocprofv3 does
+    char sym[64];
+    snprintf(sym, sizeof sym, "@gemm_gather_kernel<%d, %d, %d>", dg::gemm_tile_bm(tile), dg::gemm_tile_bn(tile), op.mode);
+    ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.plan.macs_per_row * n_rows);
     dg::launch_gemm(tile, a, (int)op.plan.pos.size(), s);
 }
 
@@ -422,7 +425,7 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
-        ProfScope ps(h, s, prof, tail_backward ? "T5fb" : "T5f", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
+        ProfScope ps(h, s, prof, tail_backward ? "T5fb@mnist_tail_mfma_kernel" : "T5f@mnist_tail_mfma_kernel", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);
     } else {
         dg::CelebaTailArgs t;
@@ -441,12 +444,12 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.dbg = h->tail_dbg;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
-            ProfScope ps(h, s, prof, "T6f", 2.0 * macs * n_rows);
+            ProfScope ps(h, s, prof, "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
             if (h->tail_mfma) dg::launch_celeba_tail_fwd_mfma(t, s); else dg::launch_celeba_tail_fwd(t, s);
         }
         dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
         if (tail_backward) {
-            ProfScope ps(h, s, prof, "T6b", 2.0 * macs * n_rows);
+            ProfScope ps(h, s, prof, "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
             if (h->tail_mfma) dg::launch_celeba_tail_bwd_mfma(t, s); else dg::launch_celeba_tail_bwd(t, s);
         }
     }
@@ -739,7 +742,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
             run_forward(h, x, g, R, /*want_y=*/last, /*tail_backward=*/!last, prof);
             if (last) continue;
             run_backward(h, g, prof);
-            ProfScope ps(h, g.s, prof, "UPD", 0.0);
+            ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
             const int64_t r0 = g.row0;
             dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
                                        h->nsplit, g.n_rows, h->latent, lr, momentum, nullptr, g.s);

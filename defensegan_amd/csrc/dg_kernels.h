@@ -95,7 +95,6 @@ void launch_select(const float* loss, const float* y, int B, int R, int P, float
 // z ~ N(0, std^2), Philox4x32-10 keyed by (seed), counter (global row, column/4)
 void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, int64_t first_row, float std,
                          hipStream_t s);
-void launch_fill_zero(float* p, int64_t n, hipStream_t s);
 
 // ---- BatchNorm with batch statistics (tflib/ops/batchnorm.py:80-93) ---------------------------
 // An activation buffer viewed as [rows, C] (rows = latent rows x positions); per-column mean / biased variance,

@@ -118,13 +118,4 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
                        (unsigned long long)seed, (long long)first_row, std);
 }
 
-__global__ __launch_bounds__(256) void fill_zero_kernel(float* p, long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = 0.f;
-}
-void launch_fill_zero(float* p, int64_t n, hipStream_t s) {
-    if (n <= 0) return;
-    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (long long)n);
-}
-
 }  // namespace dg

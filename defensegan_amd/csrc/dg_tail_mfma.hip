@@ -35,17 +35,6 @@ __device__ __forceinline__ void tail_fwd_load(const float* __restrict__ hrow, in
     }
 }
 
-// bit (kk*4 + e) of the result <-> channel 8*kk + 4*(lane>>5) + e of this lane's position is > 0 (ReluGrad mask)
-template <int C>
-__device__ __forceinline__ unsigned tail_mask_bits(const f32x4 (&a)[C / 8]) {
-    unsigned m = 0;
-#pragma unroll
-    for (int kk = 0; kk < C / 8; ++kk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m |= (a[kk][e] > 0.f ? 1u : 0u) << (kk * 4 + e);
-    return m;
-}
-
 template <int C, int NT>
 __device__ __forceinline__ void tail_fwd_compute(const f32x4 (&a)[C / 8], int q0, const f32x4 (&w)[NT][C / 8], float* sP,
                                                  int NKP, int col0, int lane) {

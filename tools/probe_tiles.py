@@ -63,7 +63,7 @@ for cfg in configs:
         torch.cuda.synchronize()
         c = gan.debug_read("clk", 4).view(torch.int64).cpu().numpy()
         clk = {"op": args.clk, "shader_ticks": int(c[0]), "rt_ticks_100MHz": int(c[1]), "GHz": round(c[0] / max(c[1], 1) * 0.1, 3)}
-    line = {p["name"]: (round(p["ms"] / p["launches"] * 1e3, 1), round(p["flops"] / p["ms"] / 1e9, 1)) for p in prof if p["launches"]}
+    line = {p["name"].split("@")[0]: (round(p["ms"] / p["launches"] * 1e3, 1), round(p["flops"] / p["ms"] / 1e9, 1)) for p in prof if p["launches"]}
     it_us = sum(v[0] for v in line.values())
     print(json.dumps({"cfg": cfg, "per_iter_us": round(it_us, 1), "loop_ms_unprofiled": round(tot, 2), "kernels": line, "clk": clk}), flush=True)
     gan.close()
