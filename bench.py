@@ -38,6 +38,18 @@ WORKLOADS = {
 }
 
 
+def traffic_for(workload, kernel, B, R):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_v3_pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be read from inside this
+    process, so the figure is only reported for the configuration it was collected on (MNIST arch, 2560 rows)."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
+    if kernel is None or not os.path.exists(path) or B * R != 2560:
+        return None
+    with open(path) as fh:
+        t = json.load(fh).get("mnist" if workload in ("mnist", "fmnist") else workload, {})
+    return t.get(kernel, {}).get("bytes_per_launch")
+
+
 def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
     """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed
     here) on this box's host cores, bounded sample, scaled to images/s at the full L."""
@@ -98,7 +110,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    distributed = world > 1
+    # DG_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to test it on a 1-GPU box)
+    distributed = world > 1 or os.environ.get("DG_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -138,6 +151,10 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    # Per-kernel durations for the roofline leg are measured LIVE inside the timed region: hipEvents on the launch
+    # stream around every kernel of each k-th GD iteration (k = --profile-stride; ~180 event pairs per step).
+    gan.profile_reset()
+    gan.profile_enable(args.profile_stride)
     t0 = time.perf_counter()
     out = None
     for i in range(args.steps):
@@ -150,21 +167,12 @@ def main():
         dist.all_gather(gathered, msg)
     barrier()
     dt = time.perf_counter() - t0
+    gan.profile_enable(0)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # Per-kernel durations for the roofline leg: hipEvents on the launch stream around every kernel of each
-    # k-th GD iteration, in one extra pass of the same workload AFTER the timed region (the timed region runs the
-    # two row groups of a batch on two streams, whose kernels interleave; the event pass runs single-stream).
-    if args.profile_stride > 0 and rank == 0:
-        gan.profile_reset()
-        gan.profile_enable(args.profile_stride)
-        step(args.warmup + args.steps)
-        torch.cuda.synchronize(dev)
-        gan.profile_enable(0)
-    barrier()
     prof = gan.profile_read()
     if rank == 0:
         images = world * B * args.steps
@@ -199,7 +207,7 @@ def main():
             "achieved": dom["tflops"] if dom else round(path_tflops, 2),
             "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": round((dom["tflops"] if dom else path_tflops) / PEAK_FP32_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic_for(args.workload, dom["kernel"] if dom else None, B, R),
             "path_achieved": round(path_tflops, 2),
             "path_frac": round(path_tflops / PEAK_FP32_TFLOPS, 4),
         }

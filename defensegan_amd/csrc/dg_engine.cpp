@@ -113,10 +113,11 @@ struct dg_handle {
     int lds_pad = 0;
     int tail_mfma = 1;
     int tail_dbg = 0;
-    int two_streams = 0;   // measured +2.8 % only; off keeps per-kernel timings comparable with rocprof
+    int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static constexpr int kMaxGroups = 4;
+    hipStream_t side_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     int clk_probe = 0;
     std::string clk_probe_op;
     long long* d_clk = nullptr;
@@ -548,11 +549,13 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     }
     if (e == hipSuccess) e = hipMemset(h->xzero, 0, (size_t)h->P * sizeof(float));
     if (e != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(weights): %s", hipGetErrorString(e)); }
-    if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < dg_handle::kMaxGroups - 1; ++i)
+        ok = hipStreamCreateWithFlags(&h->side_stream[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         dg_destroy(h);
-        return fail(DG_E_HIP, "cannot create the side stream / events");
+        return fail(DG_E_HIP, "cannot create the side streams / events");
     }
     int rc = build_plans(h);
     if (rc) { dg_destroy(h); return rc; }
@@ -582,9 +585,11 @@ int dg_destroy(dg_handle* h) {
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
-    if (h->side_stream) { (void)hipStreamSynchronize(h->side_stream); (void)hipStreamDestroy(h->side_stream); }
+    for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
+        if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     for (auto& p : h->F) fr(p);
     for (auto& p : h->Ft) fr(p);
     for (auto& p : h->bias) fr(p);
@@ -723,16 +728,22 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
     const int steps = L > 1 ? L : 1;
     // split the batch (by image) into two row groups on two streams when it is large enough to fill the chip twice
-    RowGroup grp[2];
+    RowGroup grp[dg_handle::kMaxGroups];
     int ngroups = 1;
     grp[0].row0 = 0; grp[0].n_rows = n_rows; grp[0].s = s;
-    if (h->two_streams && !h->use_bn && B >= 2 && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
-        const int b0 = (B + 1) / 2;
-        grp[0].n_rows = b0 * R;
-        grp[1].row0 = b0 * R; grp[1].n_rows = n_rows - b0 * R; grp[1].s = h->side_stream;
-        ngroups = 2;
+    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
+        ngroups = h->two_streams < B ? h->two_streams : B;
+        if (ngroups > dg_handle::kMaxGroups) ngroups = dg_handle::kMaxGroups;
+        int b_done = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int nb = (B - b_done + (ngroups - gi) - 1) / (ngroups - gi);     // images of this group
+            grp[gi].row0 = b_done * R;
+            grp[gi].n_rows = nb * R;
+            grp[gi].s = gi == 0 ? s : h->side_stream[gi - 1];
+            b_done += nb;
+        }
         HIP_TRY(hipEventRecord(h->ev_fork, s));
-        HIP_TRY(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+        for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
     }
     for (int k = 0; k < steps; ++k) {
         const bool last = (k == steps - 1);
@@ -748,9 +759,9 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
                                        h->nsplit, g.n_rows, h->latent, lr, momentum, nullptr, g.s);
         }
     }
-    if (ngroups == 2) {
-        HIP_TRY(hipEventRecord(h->ev_join, h->side_stream));
-        HIP_TRY(hipStreamWaitEvent(s, h->ev_join, 0));
+    for (int gi = 1; gi < ngroups; ++gi) {
+        HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
     }
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -878,7 +889,8 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "two_streams") {
-        h->two_streams = atoi(value) ? 1 : 0;
+        h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..4)
+        if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
         return DG_OK;
     }
     if (k == "two_stream_min_rows") {
