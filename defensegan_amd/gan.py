@@ -230,6 +230,49 @@ class DefenseGANBase(object):
             return out
         return rec.cpu().numpy() if was_numpy else rec
 
+    def reconstruct_dataset(self, splits, checkpoint_dir, batch_size=None, max_num=-1, test_again=False, seed=None):
+        """Counterpart of ``reconstruct_dataset`` (gan.py:451-587) for in-memory splits.
+
+        ``splits``: {'train'|'dev'|'test': (images [n,H,W,C] already in generator range, targets [n])}.
+        Reconstructions are cached exactly where the reference caches them, so its readers find them:
+        ``<checkpoint_dir>/recs_rr{R}_lr{lr:.5f}_iters{L}[_num{max_num}]/<split>/pickles/rec_{i:07d}_l{label}.pkl``
+        (one array per image, gan.py:504-557; directory name parsed back by whitebox.py:252-257).  Pickles are
+        written with protocol 2 so that the Python-2 reference can load them.  A batch whose pickles all exist is
+        loaded instead of recomputed unless ``test_again``.  Returns {split: [recs, targets, originals]} (gan.py:585).
+        """
+        import pickle
+        bs = int(batch_size or self.test_batch_size)
+        name = _config.rec_dir_name(int(self.rec_rr), float(self.rec_lr), int(self.rec_iters))
+        if max_num > 0:
+            name += "_num{:d}".format(max_num)
+        rets = {}
+        for split, (images, targets) in splits.items():
+            out_dir = os.path.join(checkpoint_dir, name, split)
+            pk_dir = os.path.join(out_dir, "pickles")
+            os.makedirs(pk_dir, exist_ok=True)
+            n = len(images) if max_num <= 0 else min(len(images), max_num)
+            recs = []
+            for start in range(0, n, bs):
+                end = min(n, start + bs)
+                paths = [os.path.join(pk_dir, "rec_{:07d}_l{}.pkl".format(i, targets[i])) for i in range(start, end)]
+                batch = None
+                if not test_again and all(os.path.exists(q) for q in paths):
+                    try:
+                        batch = np.stack([pickle.load(open(q, "rb"), encoding="latin1") for q in paths])
+                    except Exception:
+                        batch = None
+                if batch is None:
+                    batch = self.reconstruct(np.asarray(images[start:end], np.float32),
+                                             seed=seed, first_row=start * int(self.rec_rr))
+                    batch = np.asarray(batch.cpu().numpy() if hasattr(batch, "cpu") else batch, np.float32)
+                    for q, r in zip(paths, batch):
+                        with open(q, "wb") as f:
+                            pickle.dump(r, f, protocol=2)
+                recs.append(batch)
+            all_recs = np.concatenate(recs).reshape([-1] + list(self.image_dim)) if recs else np.zeros([0] + list(self.image_dim), np.float32)
+            rets[split] = [all_recs, np.asarray(targets[:n]), np.asarray(images[:n]).reshape([-1] + list(self.image_dim))]
+        return rets
+
     def generate(self, z):
         """G(z): generator_fn(z, is_training=False) (gan.py:399)."""
         self._ensure_handle()
@@ -320,6 +363,34 @@ class DefenseGANBase(object):
         if got < 0:
             _native.check(int(got))
         return t[:got]
+
+
+class ReconstructionLayer(object):
+    """The classifier-side wrapper of the reference (utils/network_builder.py:239-271): a layer whose forward pass
+    is the Defense-GAN projection.  ``model`` is a DefenseGANBase; ``z_init`` an optional fixed [B*R, latent] init
+    (whitebox.py --same_init); the reference's ``reconstructor_id=123`` only named TF variables."""
+
+    def __init__(self, model, z_init, input_shape, batch_size):
+        self.z_init = z_init
+        self.rec_model = model
+        self.input_shape = input_shape
+        self.batch_size = batch_size
+        self.rec = None
+
+    def set_input_shape(self, shape):
+        self.input_shape = shape
+        self.output_shape = shape
+
+    def get_output_shape(self):
+        return self.output_shape
+
+    def fprop(self, x):
+        z = self.z_init
+        if z is not None:
+            z = z[: len(x) * int(self.rec_model.rec_rr)]
+        self.rec = self.rec_model.reconstruct(x, batch_size=self.batch_size, back_prop=True, z_init_val=z,
+                                              reconstructor_id=123)
+        return self.rec
 
 
 class MnistDefenseGAN(DefenseGANBase):          # gan.py:649-685

@@ -127,3 +127,32 @@ def test_gan_object_surface_without_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(_native.NativeError):
             gan.reconstruct(np.zeros((1, 28, 28, 1), np.float32))
+
+
+def test_reconstruct_dataset_cache_layout(tmp_path):
+    """reconstruct_dataset writes the reference's cache layout (gan.py:467-478, 504-557) and reloads it."""
+    import pickle
+    from defensegan_amd.gan import MnistDefenseGAN, ReconstructionLayer
+    gan = MnistDefenseGAN(cfg={"USE_BN": False}, test_mode=True, rec_rr=2, rec_iters=5, rec_lr=10.0)
+    calls = []
+
+    def fake(images, batch_size=None, back_prop=True, reconstructor_id=0, z_init_val=None, seed=None, first_row=0, **kw):
+        calls.append((len(images), first_row, reconstructor_id))
+        return np.asarray(images) * 0.5
+    gan.reconstruct = fake
+    x = np.random.RandomState(0).rand(7, 28, 28, 1).astype(np.float32)
+    y = np.arange(7) % 3
+    out = gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)
+    d = tmp_path / "recs_rr2_lr10.00000_iters5" / "test" / "pickles"
+    assert sorted(p.name for p in d.iterdir())[0] == "rec_0000000_l0.pkl" and len(list(d.iterdir())) == 7
+    np.testing.assert_allclose(pickle.load(open(d / "rec_0000004_l1.pkl", "rb")), x[4] * 0.5)
+    assert [c[:2] for c in calls] == [(3, 0), (3, 6), (1, 12)]
+    np.testing.assert_allclose(out["test"][0], x * 0.5)
+    n_before = len(calls)
+    again = gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)       # served from the cache
+    assert len(calls) == n_before
+    np.testing.assert_allclose(again["test"][0], x * 0.5)
+    # the classifier-side wrapper forwards to reconstruct with the reference's arguments
+    layer = ReconstructionLayer(gan, None, [None, 28, 28, 1], 3)
+    np.testing.assert_allclose(layer.fprop(x[:2]), x[:2] * 0.5)
+    assert calls[-1][2] == 123
