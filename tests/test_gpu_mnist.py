@@ -191,3 +191,31 @@ def test_full_size_contractive_regime_properties():
     decided = (gap[:, 1] - gap[:, 0]) > 1e-6          # compare argmin only where the top-2 gap is resolvable
     assert (out["idx"][:nb][decided] == t["idx"][decided]).all()
     np.testing.assert_allclose(out["loss"][:nb * R], t["loss"], rtol=0.05, atol=2e-6)
+
+
+def test_cfg5_shard_shape_and_eval_harness():
+    """BASELINE config 5 per-GPU shape (10 000 images / 8 GPUs = 1250; here one ragged shard of 157 images, R=10):
+    row independence lets the oracle check a subset; model_eval_gan drives batches exactly like the reference."""
+    from defensegan_amd import gan_defense
+    O = _oracle()
+    B, R, L = 157, 10, 3
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.05, rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, "mnist", B, seed=31)
+    first_image = 1250 * 3                                   # this shard's global offset (rank 3 of 8)
+    z0 = synth.make_z(B * R, 128, seed=5, first_row=first_image * R)
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    sel = [0, 1, 155, 156]
+    xs = x[sel]
+    zs = np.concatenate([z0[b * R:(b + 1) * R] for b in sel])
+    ref = O.reconstruct(p, xs, zs, R, L, arch="mnist", dtype=np.float64)
+    got_rec = out["rec"][sel]
+    np.testing.assert_allclose(got_rec, ref["rec"], rtol=0, atol=2e-5)
+    assert (out["idx"][sel] == ref["idx"]).all()
+    # eval harness on the device path: a fixed linear "classifier", ragged batches of 50 (BATCH_SIZE default.yml:2)
+    W = np.random.RandomState(0).randn(784, 10).astype(np.float32)
+    clf = lambda im: (im.cpu().numpy() if hasattr(im, "cpu") else im).reshape(len(im), -1) @ W
+    labels = clf(x).argmax(1)
+    correct, n, roc = gan_defense.model_eval_gan(gan.reconstruct, clf, x, labels, batch_size=50, rec_rr=R, seed=9,
+                                                 first_image=first_image)
+    assert n == B and roc[1].shape == (B,) and roc[2].shape == (B,)
+    assert 0 <= correct <= B and np.isfinite(roc[2]).all() and (roc[2] >= 0).all()
