@@ -212,6 +212,7 @@ int default_tile(const std::string& name, int ncols) {
 // Fills h->ai (geometry of every activation buffer) from the architecture and use_bn.
 void describe_activations(dg_handle* h) {
     const int nd = (int)h->dec.size();
+    if ((int)h->ai.size() == nd) return;        // geometry depends on (arch, use_bn) only; keep the BN buffers
     h->ai.assign(nd, ActInfo());
     ActInfo& a0 = h->ai[0];
     a0.pitch = 4; a0.valid = 4; a0.C = h->lin_out / 16; a0.row_floats = h->lin_out;
@@ -473,6 +474,22 @@ void run_backward(dg_handle* h, const RowGroup& g, bool prof) {
     run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
 
+// (Re)builds every layer plan and re-attaches the weight pointers (dg_create, tuning options).
+int rebuild_plans(dg_handle* h) {
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = build_plans(h);
+    if (rc) return rc;
+    const size_t ndec = h->dec.size();
+    h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
+    h->B1.W = h->lin_w;
+    for (size_t d = 0; d + 1 < ndec; ++d) {
+        h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
+        h->Bd[d].W = h->Ft[d];
+    }
+    return DG_OK;
+}
+
 int check_ready(dg_handle* h) {
     if (!h) return fail(DG_E_INVALID, "null handle");
     if (!dg_weights_complete(h)) return fail(DG_E_STATE, "generator weights are not completely set (dg_set_weights)");
@@ -557,7 +574,7 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
         dg_destroy(h);
         return fail(DG_E_HIP, "cannot create the side streams / events");
     }
-    int rc = build_plans(h);
+    int rc = rebuild_plans(h);
     if (rc) { dg_destroy(h); return rc; }
     for (auto& a : h->ai) {
         if (!a.has_bn) continue;
@@ -565,12 +582,6 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
         for (float** pp : {&a.scale, &a.offset}) if (e2 == hipSuccess) e2 = hipMalloc(pp, (size_t)a.bn_C * sizeof(float));
         for (float** pp : {&a.fstats, &a.bstats}) if (e2 == hipSuccess) e2 = hipMalloc(pp, (size_t)2 * a.bn_C * sizeof(float));
         if (e2 != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(BN parameters): %s", hipGetErrorString(e2)); }
-    }
-    h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
-    h->B1.W = h->lin_w;
-    for (size_t d = 0; d + 1 < ndec; ++d) {
-        h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
-        h->Bd[d].W = h->Ft[d];
     }
     *out = h;
     return DG_OK;
@@ -867,18 +878,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         const int t = atoi(value);
         if (t < 0 || t > 3) return fail(DG_E_INVALID, "tile id must be 0..3");
         h->tile_override[k.substr(5)] = t;
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        int rc = build_plans(h);
-        if (rc) return rc;
-        const size_t ndec = h->dec.size();
-        h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
-        h->B1.W = h->lin_w;
-        for (size_t d = 0; d + 1 < ndec; ++d) {
-            h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
-            h->Bd[d].W = h->Ft[d];
-        }
-        return DG_OK;
+        return rebuild_plans(h);
     }
     if (k == "clk_probe") {      // value = op name ("F3"); read back with dg_debug_read("clk")
         HIP_TRY(hipSetDevice(h->device));
@@ -920,7 +920,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         HIP_TRY(hipDeviceSynchronize());
         h->nsplit = v;
         free_workspace(h);
-        return dg_set_option(h, "tile.__rebuild", "0");
+        return rebuild_plans(h);
     }
     return fail(DG_E_INVALID, "unknown option '%s'", key);
 }
