@@ -426,6 +426,7 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.R = R;
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
+        t.dbg = h->tail_dbg;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         ProfScope ps(h, s, prof, tail_backward ? "T5fb@mnist_tail_mfma_kernel" : "T5f@mnist_tail_mfma_kernel", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);

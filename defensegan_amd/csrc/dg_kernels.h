@@ -59,6 +59,7 @@ struct MnistTailArgs {
     int R;
     int C;               // net_dim (64)
     int do_backward;
+    int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
 };
 void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);        // VALU formulation (dg_tail.hip)
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // MFMA formulation (dg_tail_mfma.hip)

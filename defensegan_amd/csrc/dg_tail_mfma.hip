@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
             }
         };
         store_mask(a0, q0);
-        tail_fwd_compute<C, 1>(a0, wave * 32, w, sP, MN_NKP, 0, lane);
+        if (a.dbg != 2) tail_fwd_compute<C, 1>(a0, wave * 32, w, sP, MN_NKP, 0, lane);
         if (second) {
             store_mask(a1, q1);
-            tail_fwd_compute<C, 1>(a1, wave * 32 + 128, w, sP, MN_NKP, 0, lane);
+            if (a.dbg != 2) tail_fwd_compute<C, 1>(a1, wave * 32 + 128, w, sP, MN_NKP, 0, lane);
         }
     }
     __syncthreads();
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
     const float bias = a.b5[0];
     const float gscale = 2.0f / 784.0f;
     float sq = 0.f;
-    for (int p = tid; p < 784; p += 256) {
+    for (int p = tid; p < (a.dbg == 1 ? 0 : 784); p += 256) {
         const int i = p / 28, j = p - i * 28;
         const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
         float s = 0.f;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
     // ---- backward GEMM + ReluGrad (mask bits from LDS), in place over h3 ---------------------------------------------
     BwdWeights<C, 1, MN_GWP> bw;
     bw.load(a.F5, lane);
-    for (int mt = wave; mt < 7; mt += 4) {
+    for (int mt = wave; mt < (a.dbg == 3 ? 0 : 7); mt += 4) {
         const int q = mt * 32 + frow;
         const bool valid = q < 196;
         const int qq = valid ? q : 0;

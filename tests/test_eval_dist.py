@@ -156,3 +156,28 @@ def test_reconstruct_dataset_cache_layout(tmp_path):
     layer = ReconstructionLayer(gan, None, [None, 28, 28, 1], 3)
     np.testing.assert_allclose(layer.fprop(x[:2]), x[:2] * 0.5)
     assert calls[-1][2] == 123
+
+
+def test_idx_ubyte_reader_and_split(tmp_path):
+    from defensegan_amd import datasets
+    rs = np.random.RandomState(0)
+    for name, n in (("train", 60), ("t10k", 12)):
+        img = rs.randint(0, 256, size=(n, 28, 28), dtype=np.uint8)
+        lab = rs.randint(0, 10, size=n).astype(np.uint8)
+        hdr_i = np.array([0, 0, 8, 3, 0, 0, 0, n, 0, 0, 0, 28, 0, 0, 0, 28], np.uint8)
+        hdr_l = np.array([0, 0, 8, 1, 0, 0, 0, n], np.uint8)
+        (tmp_path / ("%s-images-idx3-ubyte" % name)).write_bytes(hdr_i.tobytes() + img.tobytes())
+        (tmp_path / ("%s-labels-idx1-ubyte" % name)).write_bytes(hdr_l.tobytes() + lab.tobytes())
+        if name == "t10k":
+            test_img, test_lab = img, lab
+    x, y = datasets.load_mnist_split(str(tmp_path), "test")
+    assert x.shape == (12, 28, 28, 1) and x.dtype == np.float32
+    np.testing.assert_array_equal(x[..., 0], test_img)
+    np.testing.assert_array_equal(y, test_lab)
+    xt, _ = datasets.load_mnist_split(str(tmp_path), "train")
+    xv, _ = datasets.load_mnist_split(str(tmp_path), "val")
+    assert len(xt) == 50 and len(xv) == 10                      # 5/6 : 1/6 like 50 000 : 10 000
+    g = datasets.to_generator_range(x, "mnist")
+    assert g.min() >= 0 and g.max() <= 1
+    c = datasets.to_generator_range(x, "celeba")
+    assert c.min() >= -1 and c.max() <= 1
