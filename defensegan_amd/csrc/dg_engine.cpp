@@ -112,6 +112,11 @@ struct dg_handle {
     int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
     int lds_pad = 0;
     int tail_mfma = 1;
+    int persistent = 0;            // GEMM workgroups pull tiles from an atomic queue (dg_gemm.hip)
+    int persist_wgs = 4;
+    unsigned* queue_slots = nullptr;   // one zeroed counter per GEMM launch of a call
+    size_t queue_cap = 0, queue_next = 0;
+    bool queue_active = false;         // only inside dg_reconstruct, where the counters were zeroed
     int tail_dbg = 0;
     int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
@@ -364,6 +369,12 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     a.xcd_map = h->xcd_map;
     a.lds_pad = h->lds_pad;
     a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
+    a.trace = nullptr;
+    a.queue = nullptr;
+    a.persist_wgs_per_cu = h->persist_wgs;
+    if (h->persistent && h->queue_active && h->queue_slots) {
+        a.queue = h->queue_slots + (h->queue_next++ % h->queue_cap);
+    }
     // profile entries are "<layer>@<kernel symbol>" so that bench.py can group launches the way rocprofv3 does
     char sym[64];
     snprintf(sym, sizeof sym, "@gemm_gather_kernel<%d, %d, %d>", dg::gemm_tile_bm(tile), dg::gemm_tile_bn(tile), op.mode);
@@ -597,6 +608,7 @@ int dg_destroy(dg_handle* h) {
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
+    if (h->queue_slots) { (void)hipFree(h->queue_slots); h->queue_slots = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
         if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -739,6 +751,18 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
     const int steps = L > 1 ? L : 1;
+    if (h->persistent) {
+        const size_t need = (size_t)steps * (2 * h->dec.size() + 2) * dg_handle::kMaxGroups + 16;
+        if (need > h->queue_cap) {
+            if (h->queue_slots) (void)hipFree(h->queue_slots);
+            h->queue_slots = nullptr;
+            HIP_TRY(hipMalloc(&h->queue_slots, need * sizeof(unsigned)));
+            h->queue_cap = need;
+        }
+        HIP_TRY(hipMemsetAsync(h->queue_slots, 0, h->queue_cap * sizeof(unsigned), s));
+        h->queue_next = 0;
+        h->queue_active = true;
+    }
     // split the batch (by image) into two row groups on two streams when it is large enough to fill the chip twice
     RowGroup grp[dg_handle::kMaxGroups];
     int ngroups = 1;
@@ -775,6 +799,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
         HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
     }
+    h->queue_active = false;
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_z) HIP_TRY(hipMemcpyAsync(out_z, h->z, zbytes, hipMemcpyDeviceToDevice, s));
@@ -900,6 +925,14 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "tail_dbg") {
         h->tail_dbg = atoi(value);
+        return DG_OK;
+    }
+    if (k == "persistent") {
+        h->persistent = atoi(value) ? 1 : 0;
+        return DG_OK;
+    }
+    if (k == "persist_wgs") {
+        h->persist_wgs = atoi(value);
         return DG_OK;
     }
     if (k == "tail_mfma") {

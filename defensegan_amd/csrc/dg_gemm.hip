@@ -45,23 +45,35 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
     // measurement hook: shader-clock and 100 MHz real-time stamps of workgroup 0 (effective clock under load)
     long long clk0 = 0, rt0 = 0;
     if (g.clk && blockIdx.x == 0) { clk0 = clock64(); rt0 = wall_clock64(); }
+    long long tr0 = 0;
+    if (g.trace) tr0 = wall_clock64();
 
     // Block -> (M tile, position) map.  xcd_map: workgroups are observed to land on XCD blockIdx % 8 (speed
     // only, never correctness): XCD x walks M tiles x, x+8, ... and, for each, every output position
     // (longest K first), so one M tile's input rows (1-3 MB) and the layer's filters stay in that XCD's 4 MB L2
     // while all positions that re-read them are processed.
+    // Persistent mode (g.queue != nullptr): the grid is one resident wave of workgroups; each takes tile
+    // blockIdx.x first and then pulls further tiles (same longest-K-first order) from an atomic counter, so a
+    // finished workgroup never waits for the hardware dispatcher and the pull of the NEXT tile index overlaps the
+    // current tile.  The counter word lives in HBM and is zeroed by the host before the launch.
+    const int n_tiles_total = g.n_pos * g.n_mtiles;
+    int* s_next = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);      // [1] (inside the one dynamic LDS array)
+    int tile_id = blockIdx.x;
+  for (;;) {
     int pn, mt;
     if (g.xcd_map) {
-        const int xcd = blockIdx.x & 7;
-        const int local = blockIdx.x >> 3;
+        const int xcd = tile_id & 7;
+        const int local = tile_id >> 3;
         const int mg = local / g.n_pos;
         pn = local - mg * g.n_pos;
         mt = mg * 8 + xcd;
         if (mt >= g.n_mtiles) return;
     } else {
-        pn = blockIdx.x / g.n_mtiles;
-        mt = blockIdx.x - pn * g.n_mtiles;
+        pn = tile_id / g.n_mtiles;
+        mt = tile_id - pn * g.n_mtiles;
     }
+    unsigned pulled = 0;                          // issued now, consumed after the tile (latency hidden)
+    if (g.queue && tid == 0) pulled = atomicAdd(g.queue, 1u);
     const PosEntry pe = g.pos[pn];
     const int pe_out_off = __builtin_amdgcn_readfirstlane(pe.out_off);
     const int pe_n0 = __builtin_amdgcn_readfirstlane(pe.n0);
@@ -239,6 +251,12 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         g.clk[0] = clock64() - clk0;
         g.clk[1] = wall_clock64() - rt0;
     }
+    if (g.trace && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        long long* t = g.trace + (long long)blockIdx.x * 4;
+        t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
+    }
     // ---- epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
     // Each store instruction writes two 128-B row segments (32 consecutive channels x 2 rows).
 #pragma unroll
@@ -260,19 +278,30 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
             }
         }
     }
+    if (!g.queue) return;
+    if (tid == 0) *s_next = (int)pulled + (int)gridDim.x;
+    __syncthreads();                             // every wave is done with the LDS stages; s_next is visible
+    tile_id = *s_next;
+    __syncthreads();
+    if (tile_id >= n_tiles_total) return;
+  }
 }
 
 template <int BM, int BN, int MODE>
 static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
-    const int lds = 2 * (BM + BN) * ROW_BYTES + (a.lds_pad > 0 ? a.lds_pad : 0);
+    const int lds = 2 * (BM + BN) * ROW_BYTES + 16 + (a.lds_pad > 0 ? a.lds_pad : 0);
     static int attr_lds = 0;
     if (attr_lds < lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_lds = lds;
     }
-    const unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
-                                    : (unsigned)n_pos * (unsigned)a.n_mtiles;
+    unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
+                              : (unsigned)n_pos * (unsigned)a.n_mtiles;
+    if (a.queue && !a.xcd_map) {
+        const unsigned resident = 256u * (unsigned)(a.persist_wgs_per_cu > 0 ? a.persist_wgs_per_cu : 4);
+        if (grid > resident) grid = resident;
+    }
     hipLaunchKernelGGL((gemm_gather_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, s, a);
 }
 

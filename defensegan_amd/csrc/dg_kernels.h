@@ -39,6 +39,9 @@ struct GemmArgs {
     int xcd_map;         // 1: XCD-aware block order (see dg_gemm.hip)
     int lds_pad;         // extra dynamic LDS bytes (occupancy experiments)
     long long* clk;      // optional [2]: shader-clock ticks, 100 MHz ticks spent by workgroup 0
+    unsigned* queue;     // persistent mode: zeroed tile counter (nullptr = one workgroup per tile)
+    int persist_wgs_per_cu;
+    long long* trace;    // optional [grid][4]: per-workgroup {start, end (100 MHz ticks), XCC id | CU id, chunks} (timeline probe)
 };
 
 // tile shapes: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64  (BM x BN)

@@ -12,6 +12,7 @@
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
+static long long* g_trace = nullptr;
 static double run(const dg::LayerPlan& p, int tile, int mode, int n_rows, float* A, float* W, float* Out, float* bias,
                   long long a_rowstride_override, int reps, int xcd_map) {
     dg::PosEntry* dpos; dg::TapEntry* dtaps;
@@ -24,7 +25,7 @@ static double run(const dg::LayerPlan& p, int tile, int mode, int n_rows, float*
     a.a_rowstride = a_rowstride_override >= 0 ? a_rowstride_override : p.a_rowstride;
     a.out_rowstride = p.out_rowstride; a.w_rowstride = p.w_rowstride; a.kch = p.kch; a.n_rows = n_rows;
     const int bm = dg::gemm_tile_bm(tile);
-    a.n_mtiles = (n_rows + bm - 1) / bm; a.mode = mode; a.n_pos = (int)p.pos.size(); a.xcd_map = xcd_map; a.lds_pad = 0; a.clk = nullptr;
+    a.n_mtiles = (n_rows + bm - 1) / bm; a.mode = mode; a.n_pos = (int)p.pos.size(); a.xcd_map = xcd_map; a.lds_pad = 0; a.clk = nullptr; a.trace = g_trace; a.queue = nullptr; a.persist_wgs_per_cu = 4;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     dg::launch_gemm(tile, a, a.n_pos, 0);
     CHECK(hipDeviceSynchronize());
@@ -43,6 +44,24 @@ int main(int argc, char** argv) {
     float *A, *W, *Out, *bias;
     CHECK(hipMalloc(&A, abytes)); CHECK(hipMalloc(&Out, abytes)); CHECK(hipMalloc(&W, 8 << 20)); CHECK(hipMalloc(&bias, 1 << 16));
     CHECK(hipMemset(A, 0, abytes)); CHECK(hipMemset(Out, 0, abytes)); CHECK(hipMemset(W, 0, 8 << 20)); CHECK(hipMemset(bias, 0, 1 << 16));
+    if (argc > 2) {   // timeline dump of one layer: ./gemm_probe N F2|B3|B2 > csv
+        const int tile = 3, bn = dg::gemm_tile_bn(tile);
+        dg::LayerPlan p = !strcmp(argv[2], "F2") ? dg::plan_deconv_fwd(4, 4, 7, 7, 256, 128, bn)
+                        : !strcmp(argv[2], "B3") ? dg::plan_deconv_bwd(7, 7, 14, 14, 128, 64, bn)
+                                                 : dg::plan_deconv_bwd(4, 4, 7, 7, 256, 128, bn);
+        const int mode = !strcmp(argv[2], "F2") ? dg::EPI_BIAS_RELU : dg::EPI_MASK;
+        const int grid = (int)p.pos.size() * ((N + 63) / 64);
+        CHECK(hipMalloc(&g_trace, (size_t)grid * 4 * sizeof(long long)));
+        double ms = run(p, tile, mode, N, A, W, Out, bias, -1, 2, 0);
+        std::vector<long long> h((size_t)grid * 4);
+        CHECK(hipMemcpy(h.data(), g_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long t0 = h[0];
+        for (int i = 0; i < grid; ++i) if (h[i * 4] < t0) t0 = h[i * 4];
+        printf("# %s N=%d grid=%d kernel_us=%.1f\n", argv[2], N, grid, ms * 1e3);
+        for (int i = 0; i < grid; ++i)
+            printf("%d,%lld,%lld,%lld,%lld\n", i, h[i * 4] - t0, h[i * 4 + 1] - t0, h[i * 4 + 2], h[i * 4 + 3]);
+        return 0;
+    }
     {   // steady-state check: exactly one resident wave of workgroups (256 CUs x 3), every tile 1504 chunks long
         for (int tile : {3, 2, 1, 0}) {
             const int bn = dg::gemm_tile_bn(tile), bm = dg::gemm_tile_bm(tile);
