@@ -76,18 +76,19 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
     torch.set_num_threads(cores)
     per_pass = probe / (2 * Ls - 1)
     Ls = int(max(3, min(L, (budget_s / max(per_pass, 1e-6) + 1) // 2)))
-    if Ls == L:                                   # fast host: spend the budget on more images instead
-        grow = int(min(len(x_np), 64, max(nimg, nimg * budget_s / max(per_pass * (2 * L - 1), 1e-6))))
-        if grow > nimg:
-            nimg = grow
-            z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
+    # fast host: repeat the 16-image batch (it stays cache resident; bigger batches measured slower per image)
+    reps = 1
+    if Ls == L:
+        reps = int(max(1, min(8, budget_s / max(per_pass * (2 * L - 1), 1e-6))))
     t0 = time.perf_counter()
-    T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
+    for r in range(reps):
+        T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
     dt = time.perf_counter() - t0
-    t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # work is linear in (2L-1) passes
+    t_full = dt / reps * (2 * L - 1) / (2 * Ls - 1)                            # work is linear in (2L-1) passes
+    nimg_total = nimg * reps
     return {"value": nimg / t_full, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images x R=%d x L=%d (torch-CPU autograd restatement, %d threads, %.1f s), "
-                      "scaled by (2L-1) to L=%d" % (nimg, R, Ls, cores, dt, L)}
+            "sample": "%d images (batches of %d) x R=%d x L=%d (torch-CPU autograd restatement, %d threads, %.1f s), "
+                      "scaled by (2L-1) to L=%d" % (nimg_total, nimg, R, Ls, cores, dt, L)}
 
 
 def main():
