@@ -103,6 +103,7 @@ struct dg_handle {
     float* lin_b = nullptr;
     std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
     float* tail_pack = nullptr;        // last deconv's filters in MFMA fragment order (forward tail GEMM)
+    float* tail_pack16 = nullptr;      // same, 16x16x4 fragments of the kh-aligned tiles (CelebA forward tail)
     std::map<std::string, bool> have;
 
     // ops
@@ -118,6 +119,9 @@ struct dg_handle {
     size_t queue_cap = 0, queue_next = 0;
     bool queue_active = false;         // only inside dg_reconstruct, where the counters were zeroed
     int tail_dbg = 0;
+    int tail_bwd_bands = 1;
+    int tail_fwd16 = 1;
+    int tail_stagger = 0;
     int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
     static constexpr int kMaxGroups = 4;
@@ -361,7 +365,7 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     // 128-row M tiles only pay off when there are enough of them to balance the dispatch (measured: CelebA F2 at
     // N = 1280 rows runs 254 us with 128x128 tiles vs 240 us with 64x128); same BN, so the plan is unchanged.
     int tile = op.tile;
-    if (n_rows < 2048 && dg::gemm_tile_bm(tile) == 128) tile += 1;
+    if (dg::gemm_tile_bm(tile) == 128 && (long long)op.plan.pos.size() * ((n_rows + 127) / 128) < 4096) tile += 1;
     const int bm = dg::gemm_tile_bm(tile);
     a.n_mtiles = (n_rows + bm - 1) / bm;
     a.mode = op.mode;
@@ -445,7 +449,9 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         dg::CelebaTailArgs t;
         t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
         t.F6 = h->F[nd - 1];
-        t.F6p = h->tail_pack;
+        t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
+        t.fwd16 = h->tail_fwd16;
+        t.stagger = h->tail_stagger;
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
         t.loss_part = h->loss_part + r0 * 8;
@@ -456,6 +462,7 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
         t.dbg = h->tail_dbg;
+        t.bwd_bands = h->tail_bwd_bands;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
             ProfScope ps(h, s, prof, "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
@@ -606,7 +613,7 @@ int dg_destroy(dg_handle* h) {
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
-    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack);
+    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     if (h->queue_slots) { (void)hipFree(h->queue_slots); h->queue_slots = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
@@ -685,6 +692,21 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
                             }
                 if (!h->tail_pack) HIP_TRY(hipMalloc(&h->tail_pack, pk.size() * sizeof(float)));
                 HIP_TRY(hipMemcpy(h->tail_pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+                if (s.cout == 3) {
+                    // B fragments of v_mfma_f32_16x16x4_f32, one 16-column tile per filter row kh: column
+                    // j = kw*3 + co (< 15) is kappa = 15*kh + j; lane = j + 16*g holds c = 16*kk + 4*g + e.
+                    const int kk16 = s.cin / 16;
+                    std::vector<float> p16((size_t)5 * kk16 * 64 * 4, 0.f);
+                    for (int kh = 0; kh < 5; ++kh)
+                        for (int kk = 0; kk < kk16; ++kk)
+                            for (int lane = 0; lane < 64; ++lane)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int j = lane & 15, c = kk * 16 + (lane >> 4) * 4 + e;
+                                    if (j < 15) p16[(((size_t)kh * kk16 + kk) * 64 + lane) * 4 + e] = host[(size_t)(15 * kh + j) * s.cin + c];
+                                }
+                    if (!h->tail_pack16) HIP_TRY(hipMalloc(&h->tail_pack16, p16.size() * sizeof(float)));
+                    HIP_TRY(hipMemcpy(h->tail_pack16, p16.data(), p16.size() * sizeof(float), hipMemcpyHostToDevice));
+                }
             }
             h->have[nm] = true;
             return DG_OK;
@@ -921,6 +943,18 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "two_stream_min_rows") {
         h->two_stream_min_rows = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_stagger") {
+        h->tail_stagger = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_fwd16") {
+        h->tail_fwd16 = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_bwd_bands") {
+        h->tail_bwd_bands = atoi(value);
         return DG_OK;
     }
     if (k == "tail_dbg") {

@@ -195,17 +195,19 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
         const int i = p / 28, j = p - i * 28;
         const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
         float s = 0.f;
+        // all 9 candidate taps are read unconditionally (no divergent LDS round trips): a tap that does not exist
+        // reads P[0][31], a zero-filter pad column
 #pragma unroll
         for (int ah = 0; ah < 3; ++ah) {
             const int kh = kh0 + 2 * ah;
             const int oh = (i + 1 - kh) >> 1;
-            if (kh > 4 || oh < 0 || oh >= 14) continue;
+            const bool okh = !(kh > 4 || oh < 0 || oh >= 14);
 #pragma unroll
             for (int aw = 0; aw < 3; ++aw) {
                 const int kw = kw0 + 2 * aw;
                 const int ow = (j + 1 - kw) >> 1;
-                if (kw > 4 || ow < 0 || ow >= 14) continue;
-                s += sP[(oh * 14 + ow) * MN_NKP + kh * 5 + kw];
+                const bool ok = okh && !(kw > 4 || ow < 0 || ow >= 14);
+                s += sP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
             }
         }
         const float pre = s + bias;
@@ -254,7 +256,6 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
 // =================================================================================================================
 constexpr int CE_NKP = 99;       // 75 kappa columns padded to 96 (+3: gather reads are <= 2-way bank conflicted)
 constexpr int CE_GWP = 68;       // da6 image pitch (cols are image index + 1, 67 used)
-constexpr int CE_GROWS = 11;
 
 // One workgroup per (latent row, band of 8 output rows); 6 waves, wave w owns local input row w (4 + 2 halo).
 // Measured alternatives (profiles/r01 notes): fragment-shaped global loads of H (slower than the LDS-DMA staging
@@ -371,16 +372,235 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
     if (tid == 0) a.loss_part[(long long)n * 8 + band] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) + (sred[4] + sred[5]);
 }
 
+// ---- forward tail, second formulation: v_mfma_f32_16x16x4_f32 with kh-aligned kappa tiles ------------------------------
+// The 75 filter columns are regrouped per filter row kh: tile kh holds kappa' = kw*3 + co (15 columns, padded to 16).
+// A band of 8 output rows i = 2*oh + kh - 1 needs, of its 6 input rows (local lr = oh - (4*band - 1)), only
+//     lr0: kh 3,4   lr1: kh 1..4   lr2, lr3: kh 0..4   lr4: kh 0..2   lr5: kh 0          (20 of 30 (row, kh) units)
+// so a third of the padded GEMM of the 32-wide formulation is never issued, and the 20 units split 5/5/5/5 over four
+// waves: w0 = lr2, w1 = lr3, w2 = lr1 + lr5, w3 = lr4 + lr0.  Each unit's P block [32 positions][16] (pitch 17) has its
+// own LDS slot; slot = CE16_BASE[lr] + kh.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int CE16_PITCH = 17;
+constexpr int CE16_UNIT = 32 * CE16_PITCH;                 // floats per (row, kh) unit
+constexpr int CE16_UNITS = 20;
+#ifndef CE16_DMA_AUX
+#define CE16_DMA_AUX 2                                       // nt: the streamed activation rows must not evict the filters from L1
+#endif
+// base slot per local row, 5 bits each: lr0 -> 15 (kh 3,4 -> 18,19), lr1 -> 9 (kh 1..4 -> 10..13), lr2 -> 0, lr3 -> 5,
+// lr4 -> 15 (kh 0..2 -> 15..17), lr5 -> 14
+constexpr unsigned CE16_BASE = 15u | (9u << 5) | (0u << 10) | (5u << 15) | (15u << 20) | (14u << 25);
+
 template <int C>
-__global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArgs a) {
+__global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sg = reinterpret_cast<float*>(smem);                  // [11][68][3]
+    constexpr int KK = C / 16;                                  // channel groups of 16 (4 MFMAs each)
+    constexpr int CH = C / 4;                                   // 16-B chunks per position
+    constexpr int ROWB = 32 * C * 4;                            // bytes of one staged input row
+    float* sP = reinterpret_cast<float*>(smem);                // [20][32][17], aliases the staging area
+    constexpr int MAINF = (6 * ROWB > CE16_UNITS * CE16_UNIT * 4 ? 6 * ROWB : CE16_UNITS * CE16_UNIT * 4) / 4;
+    float* sred = sP + MAINF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 3, band = blockIdx.x & 7;
+    const int b = n / a.R;
+    const float* hrow = a.h5 + (long long)n * (1024 * C);
+    const int oh_lo = 4 * band - 1;
+    const float* xrow = a.x + (long long)b * 12288;
+    // The workgroups resident on one CU run the same three phases (stage, GEMM, gather) in lockstep unless their starts
+    // are offset: workgroups k, k+256, k+512 share a CU in the first dispatch wave (measured, profiles/r01 timeline), so
+    // the later residency slots start late once and every successor inherits the offset.
+    if (a.stagger && blockIdx.x >= 256 && blockIdx.x < 1024) {
+        const int nsl = (int)(blockIdx.x >> 8) * a.stagger;
+        for (int k = 0; k < nsl; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+
+    // Output ownership: waves 0-2 own one (column j, channel co) pair each (192 pairs) for output rows 0..5 of the band,
+    // wave 3 owns three pairs per lane for rows 6, 7 -- the row is wave-uniform, the column terms are per-thread constants.
+    // x is fetched now and consumed after the GEMM phase.
+    const bool tailw = wave == 3;
+    int cjs[3];
+    cjs[0] = tailw ? 3 * lane : tid;
+    cjs[1] = tailw ? 3 * lane + 1 : tid;
+    cjs[2] = tailw ? 3 * lane + 2 : tid;
+    float xv[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const int il = tailw ? 6 + r / 3 : r;
+        xv[r] = xrow[(8 * band + il) * 192 + cjs[tailw ? r % 3 : 0]];
+    }
+
+    // wave roles: (first row, kh range), (second row, kh range)
+    const int lrA = wave == 0 ? 2 : wave == 1 ? 3 : wave == 2 ? 1 : 4;
+    const int lrB = wave == 2 ? 5 : wave == 3 ? 0 : -1;
+    const int khA_lo = wave == 2 ? 1 : 0, khA_hi = wave == 3 ? 3 : 5;
+    const int ohA = oh_lo + lrA, ohB = oh_lo + lrB;
+    const bool inA = ohA >= 0 && ohA < 32;                      // always true (lr 1..4), kept for symmetry
+    const bool inB = lrB >= 0 && ohB >= 0 && ohB < 32;
+
+    // ---- stage this wave's input rows with full-line LDS-DMA (chunk index XOR-swizzled on the source side) -----------
+    constexpr int NI = 32 * CH / 64;                            // DMA instructions per row
+    char* stA = smem + (wave < 2 ? wave : wave == 2 ? 2 : 4) * ROWB;
+    char* stB = smem + (wave == 2 ? 3 : 5) * ROWB;
+    if (a.dbg != 2 && a.dbg != 4) {
+        if (inA) {
+            const char* src = reinterpret_cast<const char*>(hrow + (long long)ohA * 32 * C);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int slot = q * 64 + lane;
+                const int pos = slot / CH, c = slot % CH;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                    (__attribute__((address_space(3))) void*)(stA + q * 1024), 16, 0, CE16_DMA_AUX);
+            }
+        }
+        if (inB) {
+            const char* src = reinterpret_cast<const char*>(hrow + (long long)ohB * 32 * C);
+#pragma unroll
+            for (int q = 0; q < NI; ++q) {
+                const int slot = q * 64 + lane;
+                const int pos = slot / CH, c = slot % CH;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                    (__attribute__((address_space(3))) void*)(stB + q * 1024), 16, 0, CE16_DMA_AUX);
+            }
+        }
+    }
+    // filter fragments of the first unit are requested before the staging wait
+    auto kh_of = [&](int st) { return wave == 2 ? (st + 1) % 5 : st; };
+    auto load_w = [&](f32x4v (&w)[KK], int kh) {
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+            w[kk] = *reinterpret_cast<const f32x4v*>(a.F6p + (((long long)kh * KK + kk) * 64 + lane) * 4);
+    };
+    f32x4v wa[KK], wb[KK];
+    load_w(wa, kh_of(0));
+    // A fragments: lane (i = lane & 15, g = lane >> 4) of position tile m holds channels 16*kk + 4*g + e
+    const int fi = lane & 15, fg = lane >> 4;
+    f32x4v avA[2][KK], avB[2][KK];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const int pos = 16 * m + fi;
+            const int off = pos * (C * 4) + (((4 * kk + fg) ^ (pos & (CH - 1))) << 4);
+            f32x4v va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (inA) va = *reinterpret_cast<const f32x4v*>(stA + off);
+            if (inB) vb = *reinterpret_cast<const f32x4v*>(stB + off);
+            avA[m][kk] = va;
+            avB[m][kk] = vb;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                            // staging is dead: P may overwrite it
+
+    // ---- GEMM: 5 (row, kh) units per wave, each 2 position tiles x KK*4 MFMAs (two independent accumulation chains);
+    // the next unit's filter fragments are in flight while the current one runs -------------------------------------------
+    // unit sequence: kh = (wave == 2 ? 1,2,3,4,0 : 0,1,2,3,4); the second row takes over at step nA
+    if (a.dbg != 2) {
+        const int nA = khA_hi - khA_lo;
+        auto unit = [&](const f32x4v (&av)[2][KK], const f32x4v (&w)[KK], int lr, int kh) {
+            f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][kk][e], w[kk][e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][kk][e], w[kk][e], acc1, 0, 0, 0);
+                }
+            // D layout: col = lane & 15 (kappa'), row = 4 * (lane >> 4) + reg (position within the tile)
+            float* pu = sP + (((CE16_BASE >> (5 * lr)) & 31) + kh) * CE16_UNIT;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pu[(4 * fg + r) * CE16_PITCH + fi] = acc0[r];
+                pu[(16 + 4 * fg + r) * CE16_PITCH + fi] = acc1[r];
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            f32x4v (&wc)[KK] = (st & 1) ? wb : wa;
+            f32x4v (&wn)[KK] = (st & 1) ? wa : wb;
+            if (st + 1 < 5) load_w(wn, kh_of(st + 1));
+            const int kh = kh_of(st);
+            if (st < nA) { if (inA) unit(avA, wc, lrA, kh); }
+            else if (inB) unit(avB, wc, lrB, kh);
+        }
+    }
+    __syncthreads();
+
+    // ---- gather (taps of matching parity) + tanh + loss + da6 ---------------------------------------------------------
+    float* grow = a.g6 + (long long)n * 12288;
+    float* yrow = a.y ? a.y + (long long)n * 12288 : nullptr;
+    const float gscale = 2.0f / 12288.0f;
+    float sq = 0.f;
+    if (a.dbg != 1) {
+        // per-pair column terms: offsets ow*17 + kw*3 + co of the <= 3 taps kw = kw0 + 2*aw
+        int colofs[3][3];
+        float bias[3];
+#pragma unroll
+        for (int c3 = 0; c3 < 3; ++c3) {
+            const int cj = cjs[c3];
+            const int j = cj / 3, co = cj - 3 * j;
+            const int kw0 = (j + 1) & 1;
+            bias[c3] = a.b6[co];
+#pragma unroll
+            for (int aw = 0; aw < 3; ++aw) {
+                const int kw = kw0 + 2 * aw;
+                const int ow = (j + 1 - kw) >> 1;
+                // a tap that does not exist reads the unit's zero pad column (kappa' = 15, zero filter column) instead
+                colofs[c3][aw] = (kw > 4 || ow < 0 || ow >= 32) ? 15 : ow * CE16_PITCH + kw * 3 + co;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int il = tailw ? 6 + r / 3 : r;                  // wave-uniform
+            const int c3 = tailw ? r % 3 : 0;
+            const int i = 8 * band + il;
+            const int kh0 = (i + 1) & 1;
+            float sacc = 0.f;
+#pragma unroll
+            for (int ah = 0; ah < 3; ++ah) {
+                const int kh = kh0 + 2 * ah;
+                const int oh = (i + 1 - kh) >> 1;
+                if (kh > 4 || oh < 0 || oh >= 32) continue;          // uniform
+                const int lr = oh - oh_lo;
+                const float* pu = sP + (((CE16_BASE >> (5 * lr)) & 31) + kh) * CE16_UNIT;
+#pragma unroll
+                for (int aw = 0; aw < 3; ++aw) {
+                    sacc += pu[tailw ? colofs[c3][aw] : colofs[0][aw]];
+                }
+            }
+            // tanh(v) = sign(v) * (1 - t) / (1 + t), t = exp(-2|v|): absolute error <= 2 ulp(1)
+            const float v = sacc + (tailw ? bias[c3] : bias[0]);
+            const float t = expf(-2.0f * __builtin_fabsf(v));
+            const float y = __builtin_copysignf((1.0f - t) / (1.0f + t), v);
+            const float d = y - xv[r];
+            sq = __builtin_fmaf(d, d, sq);
+            const int oi = i * 192 + (tailw ? cjs[c3] : cjs[0]);
+            grow[oi] = gscale * d * (1.0f - y * y);
+            if (yrow) yrow[oi] = y;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+    if (lane == 0) sred[wave] = sq;
+    __syncthreads();
+    if (tid == 0) a.loss_part[(long long)n * 8 + band] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// NB consecutive 4-input-row bands per workgroup: the filter fragments (76 registers) and the launch/ramp cost are
+// paid once per NB * 128 positions.
+template <int C, int NB>
+__global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int GROWS = 8 * NB + 3;
+    float* sg = reinterpret_cast<float*>(smem);                  // [GROWS][68][3]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int GPR = 8 / NB;                                  // workgroups per latent row
+    const int n = blockIdx.x / GPR, grp = blockIdx.x % GPR;
     const float* grow = a.g6 + (long long)n * 12288;
-    const int i_lo = 8 * band - 1;
-    for (int i = tid; i < CE_GROWS * CE_GWP * 3; i += 256) {
+    const int i_lo = 8 * NB * grp - 1;
+    for (int i = tid; i < GROWS * CE_GWP * 3; i += 256) {
         const int co = i % 3, rc = i / 3;
         const int lr = rc / CE_GWP, lc = rc - lr * CE_GWP;
         const int ii = i_lo + lr, jj = lc - 1;
@@ -391,12 +611,13 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArg
     __syncthreads();
     const int frow = lane & 31, fh = lane >> 5;
     float* hrow = a.h5 + (long long)n * (1024 * C);
-    // 4 position tiles: local input row ohl = wave, 32 positions each
-    {
-        const int ohl = wave, ow = frow;
+    // 4 * NB position tiles: local input row ohl = wave + 4 * t, 32 positions each
+#pragma unroll 1
+    for (int t = 0; t < NB; ++t) {
+        const int ohl = wave + 4 * t, ow = frow;
         f32x16 acc[C / 32];
         tail_bwd_tile<C, 3, CE_GWP>(sg, ((2 * ohl) * CE_GWP + 2 * ow) * 3, true, bw, acc, lane);
-        const int oh = 4 * band + ohl;
+        const int oh = 4 * NB * grp + ohl;
 #pragma unroll
         for (int u = 0; u < C / 32; ++u)
 #pragma unroll
@@ -408,21 +629,40 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArg
 }
 
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
-    const int lds = (192 * CE_NKP + 8) * 4;
     static bool done = false;
+    const int lds32 = (192 * CE_NKP + 8) * 4;
+    const int main16 = 6 * 32 * a.C * 4 > CE16_UNITS * CE16_UNIT * 4 ? 6 * 32 * a.C * 4 : CE16_UNITS * CE16_UNIT * 4;
+    const int lds16 = main16 + 32;
     if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
         done = true;
     }
-    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(384), lds, s, a);
-    else hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<128>), dim3(a.n_rows * 8), dim3(384), lds, s, a);
+    if (a.fwd16) {
+        if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        return;
+    }
+    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
+    else hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<128>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
+}
+
+template <int NB>
+static void launch_celeba_tail_bwd_nb(const CelebaTailArgs& a, hipStream_t s) {
+    const int lds = (8 * NB + 3) * CE_GWP * 3 * 4;
+    const unsigned grid = (unsigned)(a.n_rows * (8 / NB));
+    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<64, NB>), dim3(grid), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<128, NB>), dim3(grid), dim3(256), lds, s, a);
 }
 
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
-    const int lds = CE_GROWS * CE_GWP * 3 * 4;
-    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<128>), dim3(a.n_rows * 8), dim3(256), lds, s, a);
+    switch (a.bwd_bands) {
+        case 1: launch_celeba_tail_bwd_nb<1>(a, s); break;
+        case 4: launch_celeba_tail_bwd_nb<4>(a, s); break;
+        default: launch_celeba_tail_bwd_nb<2>(a, s); break;
+    }
 }
 
 }  // namespace dg
