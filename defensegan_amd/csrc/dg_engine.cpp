@@ -121,7 +121,8 @@ struct dg_handle {
     int tail_dbg = 0;
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
-    int tail_stagger = 0;
+    int tail_bwd_persist = 512;
+    long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
     static constexpr int kMaxGroups = 4;
@@ -392,6 +393,7 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
 struct RowGroup {
     int row0 = 0, n_rows = 0;
     hipStream_t s = nullptr;
+    int index = 0;               // which per-stream scratch (item queues) the group uses
 };
 
 dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
@@ -451,7 +453,8 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.F6 = h->F[nd - 1];
         t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
         t.fwd16 = h->tail_fwd16;
-        t.stagger = h->tail_stagger;
+        t.bwd_persist = h->tail_bwd_persist;
+        t.trace = h->d_tail_trace;
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
         t.loss_part = h->loss_part + r0 * 8;
@@ -614,6 +617,7 @@ int dg_destroy(dg_handle* h) {
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
+    if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     if (h->queue_slots) { (void)hipFree(h->queue_slots); h->queue_slots = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
@@ -798,6 +802,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
             grp[gi].row0 = b_done * R;
             grp[gi].n_rows = nb * R;
             grp[gi].s = gi == 0 ? s : h->side_stream[gi - 1];
+            grp[gi].index = gi;
             b_done += nb;
         }
         HIP_TRY(hipEventRecord(h->ev_fork, s));
@@ -909,6 +914,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
     else if (w == "clk" && h->d_clk) { src = reinterpret_cast<const float*>(h->d_clk); avail = 4; }
+    else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
         if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
@@ -945,8 +951,19 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->two_stream_min_rows = atoi(value);
         return DG_OK;
     }
-    if (k == "tail_stagger") {
-        h->tail_stagger = atoi(value);
+    if (k == "tail_trace") {     // read back with dg_debug_read("tail_trace") (int64 pairs viewed as floats)
+        HIP_TRY(hipSetDevice(h->device));
+        if (atoi(value)) {
+            if (!h->d_tail_trace) HIP_TRY(hipMalloc(&h->d_tail_trace, 4096 * 8 * sizeof(long long)));
+            HIP_TRY(hipMemset(h->d_tail_trace, 0, 4096 * 8 * sizeof(long long)));
+        } else if (h->d_tail_trace) {
+            (void)hipFree(h->d_tail_trace);
+            h->d_tail_trace = nullptr;
+        }
+        return DG_OK;
+    }
+    if (k == "tail_bwd_persist") {
+        h->tail_bwd_persist = atoi(value);
         return DG_OK;
     }
     if (k == "tail_fwd16") {

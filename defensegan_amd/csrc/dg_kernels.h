@@ -84,7 +84,8 @@ struct CelebaTailArgs {
     int dbg;             // timing experiments only: 1 = skip the gather phase, 2 = skip the GEMM phase
     int bwd_bands;       // backward MFMA tail: 4-input-row bands per workgroup (1, 2 or 4)
     int fwd16;           // forward MFMA tail: 1 = 16x16x4 kh-aligned formulation (F6p = its pack), 0 = 32x32x2
-    int stagger;         // forward MFMA tail: start delay (x ~3.4 us) per first-wave residency slot, 0 = off
+    long long* trace;    // optional per-workgroup phase cycle totals [grid][8] (persistent backward tail), or nullptr
+    int bwd_persist;     // backward MFMA tail: > 0 = persistent pipelined kernel with this many workgroups
 };
 void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s);       // VALU formulation
 void launch_celeba_tail_bwd(const CelebaTailArgs& a, hipStream_t s);

@@ -116,18 +116,36 @@ __device__ __forceinline__ void tail_bwd_tile(const float* sg, int gbase, bool v
     for (int u = 0; u < C / 32; ++u)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+    // The gathered A values are read in batches ahead of the MFMAs that consume them: read-then-use per k-step leaves
+    // the LDS latency exposed behind every MFMA pair.
+    constexpr int BATCH = NS <= 20 ? NS : (NS + 1) / 2;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        // kappa = 2s + fh -> (tap = kappa / COUT, co = kappa % COUT), tap -> (kh, kw)
-        constexpr int dummy = 0; (void)dummy;
-        const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int t0 = k0 / COUT, c0 = k0 % COUT, t1 = (k1 < NK ? k1 : k0) / COUT, c1 = (k1 < NK ? k1 : k0) % COUT;
-        const int off0 = ((t0 / 5) * GWP + (t0 % 5)) * COUT + c0;
-        const int off1 = ((t1 / 5) * GWP + (t1 % 5)) * COUT + c1;
-        float gv = sg[gbase + (fh ? off1 : off0)];
-        if (!valid) gv = 0.f;
+    for (int s0 = 0; s0 < NS; s0 += BATCH) {
+        float gv[BATCH];
 #pragma unroll
-        for (int u = 0; u < C / 32; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, bw.w[u][s], acc[u], 0, 0, 0);
+        for (int q = 0; q < BATCH; ++q) {
+            const int s = s0 + q;
+            if (s >= NS) { gv[q] = 0.f; continue; }
+            // kappa = 2s + fh -> (tap = kappa / COUT, co = kappa % COUT), tap -> (kh, kw)
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int t0 = k0 / COUT, c0 = k0 % COUT, t1 = (k1 < NK ? k1 : k0) / COUT, c1 = (k1 < NK ? k1 : k0) % COUT;
+            const int off0 = ((t0 / 5) * GWP + (t0 % 5)) * COUT + c0;
+            const int off1 = ((t1 / 5) * GWP + (t1 % 5)) * COUT + c1;
+            gv[q] = sg[gbase + (fh ? off1 : off0)];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            asm volatile("" : "+v"(gv[q]));
+            if (!valid) gv[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            const int s = s0 + q;
+            if (s >= NS) continue;
+#pragma unroll
+            for (int u = 0; u < C / 32; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[q], bw.w[u][s], acc[u], 0, 0, 0);
+        }
     }
 }
 
@@ -406,14 +424,6 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     const float* hrow = a.h5 + (long long)n * (1024 * C);
     const int oh_lo = 4 * band - 1;
     const float* xrow = a.x + (long long)b * 12288;
-    // The workgroups resident on one CU run the same three phases (stage, GEMM, gather) in lockstep unless their starts
-    // are offset: workgroups k, k+256, k+512 share a CU in the first dispatch wave (measured, profiles/r01 timeline), so
-    // the later residency slots start late once and every successor inherits the offset.
-    if (a.stagger && blockIdx.x >= 256 && blockIdx.x < 1024) {
-        const int nsl = (int)(blockIdx.x >> 8) * a.stagger;
-        for (int k = 0; k < nsl; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-
     // Output ownership: waves 0-2 own one (column j, channel co) pair each (192 pairs) for output rows 0..5 of the band,
     // wave 3 owns three pairs per lane for rows 6, 7 -- the row is wave-uniform, the column terms are per-thread constants.
     // x is fetched now and consumed after the GEMM phase.
@@ -628,6 +638,115 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArg
     }
 }
 
+// ---- backward tail, persistent and software-pipelined ---------------------------------------------------------------
+// The per-band workgroup above is three serial phases (fetch da6 + filters, 76 MFMAs per wave, 32 row stores) and every
+// workgroup on the chip runs them in lockstep, so the MFMA pipe idles during the other two.  Here a workgroup keeps the
+// filter fragments in registers for its whole life, walks a strided list of (latent row, band) items, fetches item k+1's
+// da6 image into registers while item k's MFMAs run (double-buffered LDS image, one barrier per item), and leaves its
+// stores in flight.
+constexpr int CEB_ROWS = 11, CEB_ROWF = CE_GWP * 3;          // image rows per band, floats per image row (204)
+constexpr int CEB_IMG = CEB_ROWS * CEB_ROWF;                // 2244 floats
+constexpr int CEB_PF = (CEB_IMG + 255) / 256;               // prefetch registers per thread (9)
+
+template <int C>
+__global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTailArgs a, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sg0 = reinterpret_cast<float*>(smem);                // two images [11][68][3]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    BwdWeights<C, 3, CE_GWP> bw;
+    bw.load(a.F6, lane);
+    // pin the fragments: without this the compiler re-issues the (invariant) filter loads inside the item loop
+#pragma unroll
+    for (int u = 0; u < C / 32; ++u)
+#pragma unroll
+        for (int k = 0; k < BwdWeights<C, 3, CE_GWP>::NS; ++k) asm volatile("" : "+v"(bw.w[u][k]));
+
+    // element e = tid + 256*r of the image: row lr = e / 204, c = e % 204 -> da6[(i_lo + lr), c/3 - 1, c%3] = row base + c - 3
+    auto fetch = [&](int item, float (&v)[CEB_PF]) {
+        const int n = item >> 3, band = item & 7;
+        const float* grow = a.g6 + (long long)n * 12288;
+        const int i_lo = 8 * band - 1;
+#pragma unroll
+        for (int r = 0; r < CEB_PF; ++r) {
+            const int e = tid + 256 * r;
+            const int lr = e / CEB_ROWF, c = e - lr * CEB_ROWF;
+            const int ii = i_lo + lr;
+            const bool ok = lr < CEB_ROWS && ii >= 0 && ii < 64 && c >= 3 && c < 195;
+            v[r] = ok ? grow[ii * 192 + c - 3] : 0.f;
+        }
+    };
+    auto park = [&](float* sg, const float (&v)[CEB_PF]) {
+#pragma unroll
+        for (int r = 0; r < CEB_PF; ++r)
+            if (tid + 256 * r < CEB_IMG) sg[tid + 256 * r] = v[r];
+    };
+    // Static strided item list.  Measured alternatives: an atomic item queue (one device-scope counter: 10k same-address
+    // atomics cost more than the imbalance they remove, 132 -> 189 us), filter fragments in LDS at four workgroups per CU
+    // (lifetimes spread 88..141 us, kernel 141 us), two bands per workgroup non-persistent (register pressure).
+    float pf[CEB_PF];
+    int item = blockIdx.x;
+    if (item < n_items) { fetch(item, pf); park(sg0, pf); }
+    __syncthreads();
+    int buf = 0;
+    // optional phase timing (wave 0): [0] fetch issue, [1] gather reads + MFMA issue, [2] store issue,
+    // [3] wait for the prefetch + park, [4] absolute start (100 MHz), [5] items, [6] cycles, [7] 100 MHz ticks
+    const bool tr = a.trace != nullptr;
+    long long ph[5] = {0, 0, 0, 0, 0}, t_begin = tr ? (long long)__builtin_readcyclecounter() : 0, nit = 0;
+    const long long w_begin = tr ? (long long)wall_clock64() : 0;     // constant 100 MHz counter
+    while (item < n_items) {
+        long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (tr) t0 = (long long)__builtin_readcyclecounter();
+        const int nxt = item + (int)gridDim.x;
+        if (nxt < n_items && a.dbg != 7) fetch(nxt, pf);
+        if (tr) t1 = (long long)__builtin_readcyclecounter();
+        const float* sg = sg0 + buf * CEB_IMG;
+        const int n = item >> 3, band = item & 7;
+        float* hrow = a.h5 + (long long)n * (1024 * C);
+        f32x16 acc[C / 32];
+        tail_bwd_tile<C, 3, CE_GWP>(sg, ((2 * wave) * CE_GWP + 2 * frow) * 3, true, bw, acc, lane);
+        if (tr) t2 = (long long)__builtin_readcyclecounter();
+        const int oh = 4 * band + wave;
+        bool do_store = true;
+        if (a.dbg == 5 || a.dbg == 7) {                            // timing experiments: no stores (7: no fetch either)
+            do_store = false;
+#pragma unroll
+            for (int u = 0; u < C / 32; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) do_store |= acc[u][e] == 12345.678f;
+        }
+        if (do_store) {
+#pragma unroll
+            for (int u = 0; u < C / 32; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int owr = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                    hrow[(oh * 32 + owr) * C + u * 32 + frow] = acc[u][e];
+                }
+        }
+        if (tr) t3 = (long long)__builtin_readcyclecounter();
+        if (nxt < n_items && a.dbg != 7) park(sg0 + (buf ^ 1) * CEB_IMG, pf);
+        if (tr) t4 = (long long)__builtin_readcyclecounter();
+        __syncthreads();
+        if (tr) {
+            ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t4 - t3;
+            ++nit;
+        }
+        item = nxt;
+        buf ^= 1;
+    }
+    if (tr && tid == 0 && blockIdx.x < 4096) {
+        long long* o = a.trace + (long long)blockIdx.x * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = ph[q];
+        o[4] = w_begin;
+        o[5] = nit;
+        o[6] = (long long)__builtin_readcyclecounter() - t_begin;
+        o[7] = (long long)wall_clock64() - w_begin;
+    }
+}
+
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
     static bool done = false;
     const int lds32 = (192 * CE_NKP + 8) * 4;
@@ -658,6 +777,14 @@ static void launch_celeba_tail_bwd_nb(const CelebaTailArgs& a, hipStream_t s) {
 }
 
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
+    if (a.bwd_persist > 0) {
+        const int n_items = a.n_rows * 8;
+        const int grid = n_items < a.bwd_persist ? n_items : a.bwd_persist;
+        const int lds = 2 * CEB_IMG * 4;
+        if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<64>), dim3(grid), dim3(256), lds, s, a, n_items);
+        else hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<128>), dim3(grid), dim3(256), lds, s, a, n_items);
+        return;
+    }
     switch (a.bwd_bands) {
         case 1: launch_celeba_tail_bwd_nb<1>(a, s); break;
         case 4: launch_celeba_tail_bwd_nb<4>(a, s); break;
