@@ -9,11 +9,13 @@
 // per-image first-argmin over restarts gathers the output.  No host round trip inside the loop.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -67,11 +69,19 @@ struct ActInfo {
     float* bstats = nullptr;  // [2, bn_C]
 };
 
+// Balanced tile lists of a persistent GEMM launch (one per (tile shape, M-tile count, grid) a layer has been run with).
+struct GemmSchedule {
+    int tile = 0, n_mtiles = 0, grid = 0;
+    unsigned* d_off = nullptr;     // [grid + 1]
+    unsigned* d_list = nullptr;    // [n_pos * n_mtiles]
+};
+
 struct GemmOp {
     std::string name;
     dg::LayerPlan plan;
     dg::PosEntry* d_pos = nullptr;
     dg::TapEntry* d_taps = nullptr;
+    std::vector<GemmSchedule> sched;
     int tile = 0;
     int mode = 0;
     const float* W = nullptr;
@@ -113,11 +123,8 @@ struct dg_handle {
     int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
     int lds_pad = 0;
     int tail_mfma = 1;
-    int persistent = 0;            // GEMM workgroups pull tiles from an atomic queue (dg_gemm.hip)
-    int persist_wgs = 4;
-    unsigned* queue_slots = nullptr;   // one zeroed counter per GEMM launch of a call
-    size_t queue_cap = 0, queue_next = 0;
-    bool queue_active = false;         // only inside dg_reconstruct, where the counters were zeroed
+    int persistent = 1;            // balanced persistent tile lists (dg_gemm.hip): 0 = never, 1 = where measured to pay, 2 = every layer
+    int persist_wgs = 0;           // resident workgroups per CU in persistent mode, 0 = by the tile's LDS footprint
     int tail_dbg = 0;
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
@@ -196,7 +203,57 @@ void prof_collect(dg_handle* h) {
     h->pending.clear();
 }
 
+void free_schedules(GemmOp& op) {
+    for (auto& sc : op.sched) {
+        if (sc.d_off) (void)hipFree(sc.d_off);
+        if (sc.d_list) (void)hipFree(sc.d_list);
+    }
+    op.sched.clear();
+}
+
+// Longest-processing-time-first split of a layer's tiles over `grid` persistent workgroups.  A tile's cost is its
+// K-chunk count plus a fixed prologue/epilogue share; tiles are taken in the launch order of the one-workgroup-per-
+// tile mode (positions sorted by K descending, M tiles innermost) and each goes to the least loaded workgroup, so
+// every list is itself longest-first and the lists differ by at most one short tile.
+const GemmSchedule* get_schedule(GemmOp& op, int tile, int n_mtiles, int grid) {
+    for (const auto& sc : op.sched)
+        if (sc.tile == tile && sc.n_mtiles == n_mtiles && sc.grid == grid) return &sc;
+    const int n_pos = (int)op.plan.pos.size();
+    const size_t n_tiles = (size_t)n_pos * n_mtiles;
+    const int cpt = op.plan.kch / 32;
+    std::vector<unsigned> order(n_tiles);
+    for (size_t i = 0; i < n_tiles; ++i) order[i] = (unsigned)i;
+    auto cost = [&](unsigned t) { return (long long)op.plan.pos[t / n_mtiles].tap_count * cpt + 2; };
+    std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return cost(a) > cost(b); });
+    typedef std::pair<long long, int> Load;              // (load, workgroup), smallest load on top
+    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
+    for (int w = 0; w < grid; ++w) heap.push(Load(0, w));
+    std::vector<std::vector<unsigned>> lists(grid);
+    for (unsigned t : order) {
+        Load l = heap.top();
+        heap.pop();
+        lists[l.second].push_back(t);
+        heap.push(Load(l.first + cost(t), l.second));
+    }
+    std::vector<unsigned> off(grid + 1, 0), flat;
+    flat.reserve(n_tiles);
+    for (int w = 0; w < grid; ++w) {
+        off[w] = (unsigned)flat.size();
+        flat.insert(flat.end(), lists[w].begin(), lists[w].end());
+    }
+    off[grid] = (unsigned)flat.size();
+    GemmSchedule sc;
+    sc.tile = tile; sc.n_mtiles = n_mtiles; sc.grid = grid;
+    if (hipMalloc(&sc.d_off, off.size() * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMalloc(&sc.d_list, flat.size() * sizeof(unsigned)) != hipSuccess) { (void)hipFree(sc.d_off); return nullptr; }
+    (void)hipMemcpy(sc.d_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    (void)hipMemcpy(sc.d_list, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    op.sched.push_back(sc);
+    return &op.sched.back();
+}
+
 int upload_plan(GemmOp& op) {
+    free_schedules(op);
     if (op.d_pos) { (void)hipFree(op.d_pos); op.d_pos = nullptr; }
     if (op.d_taps) { (void)hipFree(op.d_taps); op.d_taps = nullptr; }
     HIP_TRY(hipMalloc(&op.d_pos, op.plan.pos.size() * sizeof(dg::PosEntry)));
@@ -273,6 +330,7 @@ int build_plans(dg_handle* h) {
         for (auto& o : *v) {
             if (o.d_pos) (void)hipFree(o.d_pos);
             if (o.d_taps) (void)hipFree(o.d_taps);
+            free_schedules(o);
         }
     h->Fd.assign(nd - 1, GemmOp());
     h->Bd.assign(nd - 1, GemmOp());
@@ -350,7 +408,7 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
-void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+void run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
     dg::GemmArgs a;
     a.A = A;
     a.W = op.W;
@@ -375,10 +433,23 @@ void run_gemm(dg_handle* h, const GemmOp& op, const float* A, float* Out, int n_
     a.lds_pad = h->lds_pad;
     a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
     a.trace = nullptr;
-    a.queue = nullptr;
-    a.persist_wgs_per_cu = h->persist_wgs;
-    if (h->persistent && h->queue_active && h->queue_slots) {
-        a.queue = h->queue_slots + (h->queue_next++ % h->queue_cap);
+    a.sched_off = nullptr;
+    a.sched_list = nullptr;
+    a.sched_grid = 0;
+    // Measured on MI355X (probe_tiles, N = 2560 / 1280): the balanced persistent split pays where a layer has only
+    // ~1-2.5 long tiles per resident slot (backward of Generator.2: -5 % MNIST, -9 % CelebA) and costs 1-4 % on the
+    // layers with many short tiles, whose dispatch gaps are already covered by the other workgroups of the CU.
+    const bool want_persistent = h->persistent == 2 || (h->persistent == 1 && op.name == "B2");
+    if (want_persistent && !h->xcd_map) {
+        // resident workgroups per CU by the tile's LDS footprint (160 KB per CU): 64x64 -> 4, 48 KB tiles -> 3, 128x128 -> 2
+        const int lds_kb = 2 * (bm + dg::gemm_tile_bn(tile)) / 8;
+        int per_cu = h->persist_wgs > 0 ? h->persist_wgs : (lds_kb <= 32 ? 4 : lds_kb <= 48 ? 3 : 2);
+        const long long n_tiles = (long long)a.n_pos * a.n_mtiles;
+        const int grid = (int)std::min<long long>(n_tiles, 256LL * per_cu);
+        if (n_tiles > grid) {
+            const GemmSchedule* sc = get_schedule(op, tile, a.n_mtiles, grid);
+            if (sc) { a.sched_off = sc->d_off; a.sched_list = sc->d_list; a.sched_grid = sc->grid; }
+        }
     }
     // profile entries are "<layer>@<kernel symbol>" so that bench.py can group launches the way rocprofv3 does
     char sym[64];
@@ -619,7 +690,6 @@ int dg_destroy(dg_handle* h) {
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
     if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
-    if (h->queue_slots) { (void)hipFree(h->queue_slots); h->queue_slots = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
         if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -632,6 +702,7 @@ int dg_destroy(dg_handle* h) {
         if (op.d_pos) (void)hipFree(op.d_pos);
         if (op.d_taps) (void)hipFree(op.d_taps);
         op.d_pos = nullptr; op.d_taps = nullptr;
+        free_schedules(op);
     };
     frop(h->F1); frop(h->B1);
     for (auto& o : h->Fd) frop(o);
@@ -777,18 +848,6 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
     const int steps = L > 1 ? L : 1;
-    if (h->persistent) {
-        const size_t need = (size_t)steps * (2 * h->dec.size() + 2) * dg_handle::kMaxGroups + 16;
-        if (need > h->queue_cap) {
-            if (h->queue_slots) (void)hipFree(h->queue_slots);
-            h->queue_slots = nullptr;
-            HIP_TRY(hipMalloc(&h->queue_slots, need * sizeof(unsigned)));
-            h->queue_cap = need;
-        }
-        HIP_TRY(hipMemsetAsync(h->queue_slots, 0, h->queue_cap * sizeof(unsigned), s));
-        h->queue_next = 0;
-        h->queue_active = true;
-    }
     // split the batch (by image) into two row groups on two streams when it is large enough to fill the chip twice
     RowGroup grp[dg_handle::kMaxGroups];
     int ngroups = 1;
@@ -826,7 +885,6 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
         HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
     }
-    h->queue_active = false;
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_z) HIP_TRY(hipMemcpyAsync(out_z, h->z, zbytes, hipMemcpyDeviceToDevice, s));
@@ -979,7 +1037,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "persistent") {
-        h->persistent = atoi(value) ? 1 : 0;
+        h->persistent = atoi(value);
         return DG_OK;
     }
     if (k == "persist_wgs") {

@@ -52,13 +52,18 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
     // only, never correctness): XCD x walks M tiles x, x+8, ... and, for each, every output position
     // (longest K first), so one M tile's input rows (1-3 MB) and the layer's filters stay in that XCD's 4 MB L2
     // while all positions that re-read them are processed.
-    // Persistent mode (g.queue != nullptr): the grid is one resident wave of workgroups; each takes tile
-    // blockIdx.x first and then pulls further tiles (same longest-K-first order) from an atomic counter, so a
-    // finished workgroup never waits for the hardware dispatcher and the pull of the NEXT tile index overlaps the
-    // current tile.  The counter word lives in HBM and is zeroed by the host before the launch.
-    const int n_tiles_total = g.n_pos * g.n_mtiles;
-    int* s_next = reinterpret_cast<int*>(smem + 2 * STAGE_BYTES);      // [1] (inside the one dynamic LDS array)
+    // Persistent mode (g.sched_off != nullptr): the grid is one resident set of workgroups, each walking its own
+    // host-built tile list (longest K first, balanced over the workgroups): a finished tile is followed by the next
+    // one without a trip through the hardware dispatcher (measured gap between two workgroups in one CU slot:
+    // median 5.7 us, profiles/r01_v3_timeline_F2_per_workgroup.csv).
+    unsigned sched_i = 0, sched_end = 0;
     int tile_id = blockIdx.x;
+    if (g.sched_off) {
+        sched_i = g.sched_off[blockIdx.x];
+        sched_end = g.sched_off[blockIdx.x + 1];
+        if (sched_i >= sched_end) return;
+        tile_id = (int)g.sched_list[sched_i];
+    }
   for (;;) {
     int pn, mt;
     if (g.xcd_map) {
@@ -72,8 +77,6 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         pn = tile_id / g.n_mtiles;
         mt = tile_id - pn * g.n_mtiles;
     }
-    unsigned pulled = 0;                          // issued now, consumed after the tile (latency hidden)
-    if (g.queue && tid == 0) pulled = atomicAdd(g.queue, 1u);
     const PosEntry pe = g.pos[pn];
     const int pe_out_off = __builtin_amdgcn_readfirstlane(pe.out_off);
     const int pe_n0 = __builtin_amdgcn_readfirstlane(pe.n0);
@@ -278,12 +281,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
             }
         }
     }
-    if (!g.queue) return;
-    if (tid == 0) *s_next = (int)pulled + (int)gridDim.x;
-    __syncthreads();                             // every wave is done with the LDS stages; s_next is visible
-    tile_id = *s_next;
-    __syncthreads();
-    if (tile_id >= n_tiles_total) return;
+    if (!g.sched_off) return;
+    if (++sched_i >= sched_end) return;
+    tile_id = (int)g.sched_list[sched_i];
+    __syncthreads();                             // every wave is done with the LDS stages of this tile
   }
 }
 
@@ -298,10 +299,7 @@ static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
     }
     unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
                               : (unsigned)n_pos * (unsigned)a.n_mtiles;
-    if (a.queue && !a.xcd_map) {
-        const unsigned resident = 256u * (unsigned)(a.persist_wgs_per_cu > 0 ? a.persist_wgs_per_cu : 4);
-        if (grid > resident) grid = resident;
-    }
+    if (a.sched_off) grid = (unsigned)a.sched_grid;
     hipLaunchKernelGGL((gemm_gather_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, s, a);
 }
 

@@ -39,8 +39,12 @@ struct GemmArgs {
     int xcd_map;         // 1: XCD-aware block order (see dg_gemm.hip)
     int lds_pad;         // extra dynamic LDS bytes (occupancy experiments)
     long long* clk;      // optional [2]: shader-clock ticks, 100 MHz ticks spent by workgroup 0
-    unsigned* queue;     // persistent mode: zeroed tile counter (nullptr = one workgroup per tile)
-    int persist_wgs_per_cu;
+    // Persistent mode (sched_off != nullptr): the grid is one resident set of workgroups; workgroup w runs tiles
+    // sched_list[sched_off[w] .. sched_off[w+1]) (tile id = position * n_mtiles + m tile), a host-built
+    // longest-first balanced split (dg_engine.cpp, build_schedule).
+    const unsigned* sched_off;
+    const unsigned* sched_list;
+    int sched_grid;
     long long* trace;    // optional [grid][4]: per-workgroup {start, end (100 MHz ticks), XCC id | CU id, chunks} (timeline probe)
 };
 
