@@ -1,0 +1,118 @@
+"""-m gpu: the template instantiations and engine modes the default-configuration parity tests do not reach.
+
+* NET_DIM = 128 / LATENT_DIM = 64 (the C = 128 instantiations of every tail kernel, other K extents) against the
+  float64 oracle;
+* launch-shape variants of the same arithmetic (tile shapes, balanced persistent tile lists, concurrent row groups,
+  non-persistent CelebA backward tail): each output element is the same fixed-order sum whatever the launch shape, so
+  these must reproduce the default engine BIT FOR BIT;
+* formulation variants whose summation order differs (CelebA 32-wide forward tail, split-K count): tolerance.
+"""
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import defensegan_oracle as O
+    return O
+
+
+def _make(arch, net_dim=64, latent_dim=128, gain=2.0, R=2, L=3, seed=1234):
+    from defensegan_amd.gan import dataset_gan_dict
+    gan = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": latent_dim, "NET_DIM": net_dim}, test_mode=True,
+                                 rec_rr=R, rec_iters=L, rec_lr=10.0)
+    p = synth.make_weights(arch, seed=seed, gain=gain, bias_range=0.1, latent_dim=latent_dim, net_dim=net_dim)
+    assert gan.set_weights(p) == []
+    return gan, p
+
+
+@pytest.mark.parametrize("arch,net_dim,latent_dim,B,R", [
+    ("mnist", 128, 128, 3, 2), ("mnist", 128, 128, 35, 2), ("mnist", 64, 64, 4, 3),
+    ("celeba", 128, 128, 2, 2), ("celeba", 128, 128, 9, 8), ("celeba", 64, 192, 3, 2)])
+def test_other_widths_vs_oracle(arch, net_dim, latent_dim, B, R):
+    O = _oracle()
+    gan, p = _make(arch, net_dim, latent_dim, gain=2.0, R=R)
+    a = archs.make_arch(arch, latent_dim, net_dim)
+    P = int(np.prod(a.image_dim))
+    rs = np.random.RandomState(B * 31 + R)
+    zt = (rs.standard_normal((B, latent_dim)) * np.sqrt(1.0 / latent_dim)).astype(np.float32)
+    x = O.generator_forward(p, zt, arch)[0].astype(np.float32)
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=6)
+    z = (rs.standard_normal((B * R, latent_dim)) * 0.15).astype(np.float32)
+    y, loss, dz = gan.loss_grad(x, z)
+    yo, cache = O.generator_forward(p, z.astype(np.float64), arch)
+    xt = np.repeat(x.astype(np.float64), R, axis=0)
+    lo = ((yo - xt) ** 2).reshape(B * R, -1).mean(axis=1)
+    go = O.generator_backward(p, cache, 2.0 / P * (yo - xt), arch)
+    # fp32 vs float64: the output pre-activation is a sum of up to 1600 products; the gate scales with its magnitude
+    atol = 1e-6 * max(5.0, float(np.abs(cache["pre"][-1]).max()))
+    np.testing.assert_allclose(y, yo, rtol=0, atol=atol)
+    np.testing.assert_allclose(loss, lo, rtol=1e-5)
+    kink = np.zeros(B * R, bool)
+    for a_pre, (_, _, _, act, _) in zip(cache["pre"][1:], O._arch_layers(arch)):
+        if act == "relu":
+            kink |= (np.abs(a_pre).reshape(B * R, -1).min(axis=1) < 1e-6)
+    kink |= (np.abs(cache["pre"][0]).reshape(B * R, -1).min(axis=1) < 1e-6)
+    scale = np.abs(go).max()
+    err = np.abs(dz - go).max(axis=1) / scale
+    assert kink.sum() <= max(2, 0.3 * B * R)
+    assert (err[~kink] < 1e-5).all(), err[~kink].max()
+    assert (err < 0.2).all(), err.max()
+
+
+def _run(gan, x, z0):
+    d = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    return {k: (v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)) for k, v in d.items()}
+
+
+BITWISE = {
+    "mnist": [{"persistent": 0}, {"persistent": 2}, {"two_streams": 2, "two_stream_min_rows": 64},
+              {"persistent": 2, "tile.F2": 0, "tile.B3": 0, "tile.B2": 0, "tile.F3": 2},
+              {"tile.F2": 1, "tile.B3": 1, "tile.B2": 2, "tile.F1": 1}],
+    "celeba": [{"persistent": 0}, {"persistent": 2, "tile.F2": 0, "tile.B3": 1}, {"tail_bwd_persist": 0},
+               {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300}],
+}
+
+
+@pytest.mark.parametrize("arch,B,R", [("mnist", 140, 10), ("celeba", 70, 10)])
+def test_launch_shape_variants_are_bit_identical(arch, B, R):
+    """1400 / 700 rows: more tiles than resident slots, so the persistent lists and both tail item loops iterate."""
+    a = archs.make_arch(arch)
+    gan, p = _make(arch, R=R, L=3)
+    rs = np.random.RandomState(7)
+    x = gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32))
+    x = np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32)
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=8)
+    z0 = synth.make_z(B * R, 128, seed=9)
+    ref = _run(gan, x, z0)
+    assert np.isfinite(ref["loss"]).all()
+    for opts in BITWISE[arch]:
+        g2, _ = _make(arch, R=R, L=3)
+        for k, v in opts.items():
+            g2.set_option(k, v)
+        got = _run(g2, x, z0)
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+@pytest.mark.parametrize("arch,opts", [("celeba", {"tail_fwd16": 0}), ("mnist", {"nsplit": 4}), ("mnist", {"nsplit": 16}),
+                                       ("celeba", {"tail_mfma": 0})])
+def test_reordered_formulations_agree_to_rounding(arch, opts):
+    a = archs.make_arch(arch)
+    B, R = 6, 3
+    gan, p = _make(arch, R=R, L=1)
+    rs = np.random.RandomState(11)
+    x = gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32))
+    x = np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32)
+    z = (rs.standard_normal((B * R, 128)) * 0.15).astype(np.float32)
+    y0, l0, g0 = gan.loss_grad(x, z)
+    g2, _ = _make(arch, R=R, L=1)
+    for k, v in opts.items():
+        g2.set_option(k, v)
+    y1, l1, g1 = g2.loss_grad(x, z)
+    np.testing.assert_allclose(y1, y0, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    np.testing.assert_allclose(g1, g0, rtol=0, atol=2e-5 * np.abs(g0).max())
