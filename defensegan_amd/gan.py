@@ -144,17 +144,30 @@ class DefenseGANBase(object):
         return missing
 
     def load_generator(self, ckpt_path: Optional[str] = None):
-        """Counterpart of ``load_generator`` (gan.py:85-87).  ``ckpt_path`` is an ``.npz`` weight pack whose
-        keys are the tflib parameter names (a TF1 checkpoint has to be converted on a TF-capable machine:
-        TensorFlow is not available here)."""
+        """Counterpart of ``load_generator`` (gan.py:85-87 -> base_model.py:294-335).  ``ckpt_path`` is
+
+        * an ``.npz`` weight pack whose keys are the tflib parameter names (or a directory holding ``generator.npz``), or
+        * a TensorFlow checkpoint written by the reference: a directory with a ``checkpoint`` state file (resolved like
+          ``tf.train.get_checkpoint_state``), a checkpoint prefix, or its ``.index`` file -- read without TensorFlow by
+          ``tf_checkpoint`` (V2 tensor-bundle format; variables are matched by the last component of their name, so
+          ``Generator.Input/Generator.Input.W`` and optimizer slots in the same file are handled).
+        """
         if ckpt_path is None:
-            raise ValueError("load_generator needs the path of an .npz weight pack")
-        if os.path.isdir(ckpt_path):
+            ckpt_path = getattr(self, "checkpoint_dir", None)
+        if ckpt_path is None:
+            raise ValueError("load_generator needs the path of an .npz weight pack or of a TensorFlow checkpoint")
+        if os.path.isdir(ckpt_path) and os.path.exists(os.path.join(ckpt_path, "generator.npz")):
             ckpt_path = os.path.join(ckpt_path, "generator.npz")
-        with np.load(ckpt_path) as f:
-            missing = self.set_weights({k: f[k] for k in f.files})
+        if ckpt_path.endswith(".npz"):
+            with np.load(ckpt_path) as f:
+                weights = {k: f[k] for k in f.files}
+        else:
+            from . import tf_checkpoint
+            expected = archs.weight_shapes(self._arch, bool(self.use_bn))
+            weights = tf_checkpoint.generator_weights(ckpt_path, expected.keys())
+        missing = self.set_weights(weights)
         if missing:
-            raise ValueError("weight pack %s lacks %s" % (ckpt_path, ", ".join(missing)))
+            raise ValueError("%s lacks %s" % (ckpt_path, ", ".join(missing)))
         return True
 
     # ------------------------------------------------------------------ the hot path

@@ -116,3 +116,30 @@ def test_reordered_formulations_agree_to_rounding(arch, opts):
     np.testing.assert_allclose(y1, y0, rtol=0, atol=2e-6)
     np.testing.assert_allclose(l1, l0, rtol=2e-6)
     np.testing.assert_allclose(g1, g0, rtol=0, atol=2e-5 * np.abs(g0).max())
+
+
+def test_load_generator_from_tensorflow_checkpoint(tmp_path):
+    """a reference-style checkpoint directory (scoped names, optimizer slots, other networks) loads through
+    ``load_generator`` and gives the generator the same weights as ``set_weights``."""
+    from defensegan_amd import tf_checkpoint
+    from defensegan_amd.gan import dataset_gan_dict
+    gan, p = _make("mnist", R=2, L=2)
+    t = {}
+    for name, a in p.items():
+        scope = name.rsplit(".", 1)[0]
+        t["%s/%s" % (scope, name)] = a
+        t["%s/%s/Adam" % (scope, name)] = np.zeros_like(a)
+    t["Discriminator.1/Discriminator.1.Filters"] = np.ones((5, 5, 1, 64), np.float32)
+    t["global_step"] = np.array(7, np.int64)
+    tf_checkpoint.write_checkpoint(str(tmp_path / "GAN.model-7"), t)
+    g2 = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True, rec_rr=2, rec_iters=2)
+    assert not g2.initialized
+    assert g2.load_generator(str(tmp_path)) is True
+    z = synth.make_z(5, 128, seed=2)
+    assert np.array_equal(np.asarray(g2.generate(z)), np.asarray(gan.generate(z)))
+    bad = dict(t)
+    del bad["Generator.3/Generator.3.Filters"]
+    tf_checkpoint.write_checkpoint(str(tmp_path / "bad" / "m"), bad)
+    g3 = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True)
+    with pytest.raises(ValueError, match="Generator.3.Filters"):
+        g3.load_generator(str(tmp_path / "bad"))

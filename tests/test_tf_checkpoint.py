@@ -1,0 +1,119 @@
+"""CPU: the TensorFlow checkpoint (V2 tensor bundle) reader of SURVEY.md 8f-N1.
+
+No checkpoint written by a real TensorFlow is available (the reference ships none, TF cannot be installed), so these
+tests pin the reader against (a) bytes assembled by hand from the published format description and (b) files produced by
+the module's own writer -- "parity unpinned", as the module header says."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth, tf_checkpoint as T
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors for CRC-32C
+    assert T.crc32c(b"") == 0
+    assert T.crc32c(b"\x00" * 32) == 0x8A9136AA
+    assert T.crc32c(b"\xff" * 32) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(b"123456789") == 0xE3069283
+    # incremental == one-shot ; mask is a rotation plus a constant (crc32c.h)
+    assert T.crc32c(b"6789", T.crc32c(b"12345")) == 0xE3069283
+    assert T.mask_crc(0) == 0xA282EAD8
+
+
+def test_varint_and_proto_wire_format():
+    assert T._put_varint(0) == b"\x00" and T._put_varint(300) == b"\xac\x02"
+    assert T._get_varint(b"\xac\x02\x07", 0) == (300, 2)
+    # BundleEntryProto {dtype: DT_FLOAT(1), shape {dim {size: 5} dim {size: 5}}, offset: 16, size: 100, crc32c: fixed32}
+    shape = b"\x12\x02\x08\x05" * 2
+    buf = b"\x08\x01" + b"\x12" + bytes([len(shape)]) + shape + b"\x20\x10" + b"\x28\x64" + b"\x35" + struct.pack("<I", 0xDEADBEEF)
+    e = T._parse_entry("v", buf)
+    assert (e.dtype, e.shape, e.shard, e.offset, e.size, e.crc, e.sliced) == (1, (5, 5), 0, 16, 100, 0xDEADBEEF, False)
+
+
+def test_hand_assembled_block_with_prefix_compression():
+    # entries: "Generator.2" -> "a", "Generator.3" (shares 10 bytes) -> "bc", restart, "z" -> ""
+    blk = b"\x00\x0b\x01Generator.2a" + b"\x0a\x01\x023bc"
+    r2 = len(blk)
+    blk += b"\x00\x01\x00z"
+    blk += struct.pack("<III", 0, r2, 2)
+    assert T._parse_block(blk) == [(b"Generator.2", b"a"), (b"Generator.3", b"bc"), (b"z", b"")]
+
+
+def test_snappy_literal_and_copy():
+    # "abcdabcdabcd": literal "abcd" + copy(offset 4, length 8)
+    src = bytes([12]) + bytes([(4 - 1) << 2]) + b"abcd" + bytes([((8 - 4) << 2) | 1, 4])
+    assert T._snappy_uncompress(src) == b"abcdabcdabcd"
+
+
+def _ref_style_tensors(arch="mnist", use_bn=False):
+    p = synth.make_weights(arch, seed=7, gain=1.0, bias_range=0.1, use_bn=use_bn, bn_jitter=0.1 if use_bn else 0.0)
+    t = {}
+    for name, a in p.items():
+        scope = name.rsplit(".", 1)[0]                       # Generator.Input.W -> scope Generator.Input
+        t["%s/%s" % (scope, name)] = a
+        t["%s/%s/Adam" % (scope, name)] = np.zeros_like(a)   # optimizer slots share the file
+        t["%s/%s/Adam_1" % (scope, name)] = np.ones_like(a)
+    rs = np.random.RandomState(3)
+    for i in range(40):                                      # enough keys for several 4 KB index blocks
+        t["Discriminator.%d/Discriminator.%d.Filters" % (i, i)] = rs.standard_normal((3, 3, 2, 2)).astype(np.float32)
+    t["global_step"] = np.array(12345, np.int64)
+    t["beta1_power"] = np.array(0.5, np.float32)
+    return p, t
+
+
+@pytest.mark.parametrize("arch,use_bn", [("mnist", False), ("celeba", True)])
+def test_write_read_round_trip_and_generator_selection(tmp_path, arch, use_bn):
+    p, t = _ref_style_tensors(arch, use_bn)
+    prefix = str(tmp_path / "ckpt" / "GAN.model-12345")
+    T.write_checkpoint(prefix, t)
+    assert os.path.exists(prefix + ".index") and os.path.exists(prefix + ".data-00000-of-00001")
+    with open(prefix + ".index", "rb") as f:
+        raw = f.read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57
+    listed = T.list_variables(prefix)
+    assert [n for n, _, _ in listed] == sorted(t, key=lambda s: s.encode())
+    assert dict((n, s) for n, s, _ in listed)["global_step"] == ()
+    back = T.read_checkpoint(prefix)
+    assert set(back) == set(t)
+    for k in t:
+        assert back[k].dtype == t[k].dtype and back[k].shape == t[k].shape and np.array_equal(back[k], t[k]), k
+    # directory / prefix / index-file spellings all resolve (base_model.py:311-323)
+    d = str(tmp_path / "ckpt")
+    assert T.latest_checkpoint(d) == prefix
+    for spelling in (d, prefix, prefix + ".index", prefix + ".data-00000-of-00001"):
+        assert T.resolve_prefix(spelling) == prefix
+    a = archs.make_arch(arch)
+    got = T.generator_weights(d, archs.weight_shapes(a, use_bn).keys())
+    assert set(got) == set(p)
+    for k in p:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], p[k]), k
+
+
+def test_corruption_and_errors_are_reported(tmp_path):
+    _, t = _ref_style_tensors("mnist")
+    prefix = str(tmp_path / "m")
+    T.write_checkpoint(prefix, t, write_state=False)
+    assert T.latest_checkpoint(str(tmp_path)) is None
+    with pytest.raises(T.CheckpointError):
+        T.resolve_prefix(str(tmp_path))
+    with pytest.raises(T.CheckpointError):
+        T.read_checkpoint(prefix, names=["no/such/variable"])
+    data = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(data, "rb").read())
+    raw[100] ^= 0x40
+    open(data, "wb").write(bytes(raw))
+    with pytest.raises(T.CheckpointError, match="checksum"):
+        T.read_checkpoint(prefix)
+    assert len(T.read_checkpoint(prefix, verify=False)) == len(t)       # explicit opt-out still reads
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[10] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(T.CheckpointError):
+        T.list_variables(prefix)
+    open(prefix + ".index", "wb").write(b"not a table")
+    with pytest.raises(T.CheckpointError):
+        T.list_variables(prefix)
