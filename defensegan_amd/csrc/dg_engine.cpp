@@ -129,6 +129,7 @@ struct dg_handle {
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
     int tail_bwd_persist = 512;
+    int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
     int two_stream_min_rows = 1024;
@@ -515,6 +516,8 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
         t.dbg = h->tail_dbg;
+        t.pipe = h->tail_pipe;
+        t.trace = h->d_tail_trace;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         ProfScope ps(h, s, prof, tail_backward ? "T5fb@mnist_tail_mfma_kernel" : "T5f@mnist_tail_mfma_kernel", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);
@@ -1018,6 +1021,10 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
             (void)hipFree(h->d_tail_trace);
             h->d_tail_trace = nullptr;
         }
+        return DG_OK;
+    }
+    if (k == "tail_pipe") {
+        h->tail_pipe = atoi(value);
         return DG_OK;
     }
     if (k == "tail_bwd_persist") {

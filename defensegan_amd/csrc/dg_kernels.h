@@ -67,6 +67,8 @@ struct MnistTailArgs {
     int C;               // net_dim (64)
     int do_backward;
     int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
+    long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr
+    int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
 };
 void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);        // VALU formulation (dg_tail.hip)
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // MFMA formulation (dg_tail_mfma.hip)

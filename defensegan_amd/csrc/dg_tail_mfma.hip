@@ -149,6 +149,57 @@ __device__ __forceinline__ void tail_bwd_tile(const float* sg, int gbase, bool v
     }
 }
 
+// Variants with the filter fragments in LDS instead of registers (the pipelined MNIST kernel keeps two rows of A
+// fragments per wave and has no registers left for 58 filter values).
+//   forward:  sWf[(kk*64 + lane)*4 + e]  = F[kappa = lane&31][c = 8*kk + 4*(lane>>5) + e]   (one kappa tile)
+//   backward: sWb[(s*64 + lane)*U + u]   = F[kappa = 2*s + (lane>>5)][c = 32*u + (lane&31)], U = C/32
+template <int C>
+__device__ __forceinline__ void tail_fwd_compute_ldsw(const f32x4 (&a)[C / 8], int q0, const float* sWf, float* sP, int NKP, int lane) {
+    const int frow = lane & 31, fh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < C / 8; ++kk) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk][e], w[e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * fh;
+        sP[(q0 + r) * NKP + frow] = acc[e];
+    }
+}
+
+template <int C, int COUT, int GWP>
+__device__ __forceinline__ void tail_bwd_tile_ldsw(const float* sg, int gbase, bool valid, const float* sWb, f32x16 (&acc)[C / 32], int lane) {
+    constexpr int NK = 25 * COUT, NS = (NK + 1) / 2, U = C / 32;
+    const int fh = lane >> 5;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+    float gv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int k0 = 2 * s, k1 = 2 * s + 1;
+        const int t0 = k0 / COUT, c0 = k0 % COUT, t1 = (k1 < NK ? k1 : k0) / COUT, c1 = (k1 < NK ? k1 : k0) % COUT;
+        const int off0 = ((t0 / 5) * GWP + (t0 % 5)) * COUT + c0;
+        const int off1 = ((t1 / 5) * GWP + (t1 % 5)) * COUT + c1;
+        gv[s] = sg[gbase + (fh ? off1 : off0)];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float g = valid ? gv[s] : 0.f;
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = sWb[(s * 64 + lane) * U + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(g, w[u], acc[u], 0, 0, 0);
+    }
+}
+
 // =================================================================================================================
 // MNIST: Generator.5 (C -> 1, 14x14 -> 28x28) + sigmoid + loss + backward, one workgroup per latent row
 // =================================================================================================================
@@ -263,7 +314,253 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
     }
 }
 
+// ---- pipelined variant: one persistent 12-wave workgroup per CU, MFMA waves and gather waves work on different rows ----
+// The fused kernel above runs load -> forward GEMM -> gather -> backward GEMM -> store strictly in sequence per latent
+// row; the MFMA pipe idles during the gather and both memory phases.  Here waves 0-7 ("M", tile = wave, tile 7 idle)
+// own the two GEMMs and waves 8-11 ("G") own the gather/sigmoid/loss.  In step t (one barrier per step)
+//     M:  A fragments of row t+1 from the wave's LDS stage, LDS-DMA of row t+2 into it | backward GEMM + masked store of
+//         row t-1 | forward GEMM of row t+1
+//     G:  gather + sigmoid + loss + da5 image of row t
+// with P, the da5 image and the ReluGrad bits double-buffered by row parity, so the three stages of three consecutive
+// rows overlap and the A fragments have a whole step to arrive.  Rows of a workgroup: blockIdx.x + k * gridDim.x.
+// Measured (tools/tail_trace_mnist.py, N = 2560): 86 -> 78 us; a step is ~17 k cycles of which the 8 DMA instructions
+// take 2.4 k and the 32 row stores ~3 k to ISSUE (the memory pipes are saturated in bursts: 100 KB per CU per step);
+// spreading them between the forward MFMA groups made it worse (125 us: every stalled VMEM issue then blocks MFMAs);
+// offsetting the workgroups' start times to de-phase the bursts changed nothing.
+template <int C>
+__global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PSZ = 224 * MN_NKP, GSZ = MN_GR * MN_GWP, MSZ = 224 * (C / 32);
+    float* sP = reinterpret_cast<float*>(smem);                  // [2][224][MN_NKP]
+    float* sg = sP + 2 * PSZ;                                    // [2][31][32]
+    unsigned* smask = reinterpret_cast<unsigned*>(sg + 2 * GSZ); // [2][224][C/32]
+    float* sred = reinterpret_cast<float*>(smask + 2 * MSZ);     // [2][4]
+    float* sWf = sred + 8;                                       // forward filter fragments [C/8][64][4]
+    float* sWb = sWf + (C / 8) * 256;                            // backward filter fragments [13][64][C/32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool mrole = wave < 8;
+    const bool mwork = wave < 7;                                 // 7 position tiles
+    char* stage = reinterpret_cast<char*>(sWb + 13 * 64 * (C / 32)) + (wave & 7) * (32 * C * 4);   // this M wave's A tile [32][C], LDS-DMA target
+    const int tile = wave;
+    const int gt = tid - 512;                                    // gather thread id (G waves)
+    const int gw = wave - 8;
+    const int n_my = ((int)a.n_rows - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto row_of = [&](int k) { return (long long)blockIdx.x + (long long)k * gridDim.x; };
+
+    for (int i = tid; i < 2 * GSZ; i += 768) sg[i] = 0.f;       // zero borders of both da5 images, written once
+
+    for (int i = tid; i < (C / 8) * 256; i += 768) {
+        const int e = i & 3, l = (i >> 2) & 63, kk = i >> 8;
+        const int kappa = l & 31, c = kk * 8 + (l >> 5) * 4 + e;
+        sWf[i] = kappa < 25 ? a.F5[kappa * C + c] : 0.f;
+    }
+    for (int i = tid; i < 13 * 64 * (C / 32); i += 768) {
+        const int u = i % (C / 32), l = (i / (C / 32)) & 63, st = i / (64 * (C / 32));
+        const int kappa = 2 * st + (l >> 5);
+        sWb[i] = kappa < 25 ? a.F5[kappa * C + u * 32 + (l & 31)] : 0.f;
+    }
+    const int q = tile * 32 + frow;                              // this lane's position in the M role
+    const bool qvalid = q < 196;
+    // A tile of row k: 32 positions x C floats = one contiguous 8 KB run, staged with full-line LDS-DMA into this wave's
+    // private region (16-B chunk index XOR-swizzled with the position on the source side: conflict-free b128 reads).
+    constexpr int CH = C / 4;                                    // 16-B chunks per position
+    constexpr int NI = 32 * CH / 64;                             // DMA instructions per full tile
+    auto stage_row = [&](int k) {
+        const char* src = reinterpret_cast<const char*>(a.h3 + row_of(k) * (196 * C) + (long long)tile * 32 * C);
+        const int ni = tile < 6 ? NI : (196 - 192) * CH / 64;    // the last tile holds 4 positions
+#pragma unroll
+        for (int qi = 0; qi < NI; ++qi) {
+            if (qi >= ni) break;
+            const int slot = qi * 64 + lane;
+            const int pos = slot / CH, c = slot % CH;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                (__attribute__((address_space(3))) void*)(stage + qi * 1024), 16, 0, 0);
+        }
+    };
+    // younger_stores: the wave issued its 32 backward row stores AFTER the DMA being waited for.  VMEM operations retire
+    // in order, so the DMA has landed once at most those 32 are outstanding -- waiting for vmcnt(0) would also wait for
+    // the stores' HBM acknowledgements.  (Tile 6 issues fewer stores: it waits for everything.)
+    auto read_frags = [&](f32x4 (&av)[C / 8], bool younger_stores) {
+        if (younger_stores && tile < 6) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < C / 8; ++kk) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (qvalid) v = *reinterpret_cast<const f32x4*>(stage + frow * (C * 4) + (((kk * 2 + fh) ^ (frow & (CH - 1))) << 4));
+            av[kk] = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // ReluGrad bits, transposed: word mk[tile*C + c] has bit p set iff h3[position 32*tile + p][channel c] > 0.  A wave
+    // ballot over "fragment element > 0" is exactly two such words (lanes 0-31 = the 32 positions for channel 8kk+e,
+    // lanes 32-63 for channel 8kk+4+e), and the backward epilogue needs one word per accumulator block instead of 16.
+    auto fwd = [&](int k, const f32x4 (&av)[C / 8]) {
+        unsigned* mk = smask + (k & 1) * MSZ + tile * C;
+#pragma unroll
+        for (int kk = 0; kk < C / 8; ++kk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long bal = __ballot(av[kk][e] > 0.f);
+                if (lane < 2) mk[8 * kk + 4 * lane + e] = lane ? (unsigned)(bal >> 32) : (unsigned)bal;
+            }
+        tail_fwd_compute_ldsw<C>(av, tile * 32, sWf, sP + (k & 1) * PSZ, MN_NKP, lane);
+    };
+    auto bwd = [&](int k) {
+        const unsigned* mk = smask + (k & 1) * MSZ + tile * C;
+        float* hrow = a.h3 + row_of(k) * (196 * C);
+        const int qq = qvalid ? q : 0;
+        const int oh = qq / 14, ow = qq - oh * 14;
+        f32x16 acc[C / 32];
+        tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, (2 * oh) * MN_GWP + 2 * ow, qvalid, sWb, acc, lane);
+#pragma unroll
+        for (int u = 0; u < C / 32; ++u) {
+            const unsigned mw = mk[u * 32 + frow];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pr = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                const int qr = tile * 32 + pr;
+                if (qr < 196) hrow[qr * C + u * 32 + frow] = ((mw >> pr) & 1u) ? acc[u][e] : 0.f;
+            }
+        }
+    };
+    const float bias = a.b5[0];
+    const float gscale = 2.0f / 784.0f;
+    auto load_x = [&](int k, float (&xv)[4]) {
+        const float* xrow = a.x + (row_of(k) / a.R) * 784;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            xv[r] = p < 784 ? xrow[p] : 0.f;
+        }
+    };
+    auto gather = [&](int k, const float (&xv)[4]) {
+        const float* pP = sP + (k & 1) * PSZ;
+        float* pg = sg + (k & 1) * GSZ;
+        const long long n = row_of(k);
+        float sq = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            if (p >= 784) break;
+            const int i = p / 28, j = p - i * 28;
+            const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
+            float sacc = 0.f;
+#pragma unroll
+            for (int ah = 0; ah < 3; ++ah) {
+                const int kh = kh0 + 2 * ah;
+                const int oh = (i + 1 - kh) >> 1;
+                const bool okh = !(kh > 4 || oh < 0 || oh >= 14);
+#pragma unroll
+                for (int aw = 0; aw < 3; ++aw) {
+                    const int kw = kw0 + 2 * aw;
+                    const int ow = (j + 1 - kw) >> 1;
+                    const bool ok = okh && !(kw > 4 || ow < 0 || ow >= 14);
+                    sacc += pP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
+                }
+            }
+            const float y = 1.0f / (1.0f + expf(-(sacc + bias)));
+            const float d = y - xv[r];
+            sq = __builtin_fmaf(d, d, sq);
+            pg[(i + 1) * MN_GWP + (j + 1)] = gscale * d * y * (1.0f - y);
+            if (a.y) a.y[n * 784 + p] = y;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+        if (lane == 0) sred[(k & 1) * 4 + gw] = sq;
+    };
+    auto finish_loss = [&](int k) {       // after the barrier that follows gather(k)
+        const float* r4 = sred + (k & 1) * 4;
+        a.loss[row_of(k)] = ((r4[0] + r4[1]) + (r4[2] + r4[3])) * (1.0f / 784.0f);
+    };
+
+    // ---- the two roles run separate loops with the same barrier sequence: sg-zero | prologue | one per step ------------
+    if (mrole) {
+        f32x4 A[C / 8];
+        if (mwork) stage_row(0);
+        __syncthreads();                                         // sg zeroed, filter fragments in LDS
+        if (mwork) {
+            read_frags(A, false);
+            if (n_my > 1) stage_row(1);
+            fwd(0, A);
+        }
+        __syncthreads();
+        const bool tr = a.trace != nullptr && wave == 0;
+        long long ph[5] = {0, 0, 0, 0, 0};
+        const long long tb = tr ? (long long)__builtin_readcyclecounter() : 0, wb = tr ? (long long)wall_clock64() : 0;
+        for (int t = 0; t <= n_my; ++t) {
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+            if (tr) c0 = (long long)__builtin_readcyclecounter();
+            if (mwork) {
+                if (t + 1 < n_my) {
+                    read_frags(A, t >= 2);                       // row t+1 (staged one step ago, before bwd(t-2)'s stores)
+                    if (tr) c1 = (long long)__builtin_readcyclecounter();
+                    if (t + 2 < n_my) stage_row(t + 2);          // lands during this step's two GEMMs
+                }
+                if (tr) c2 = (long long)__builtin_readcyclecounter();
+                if (t >= 1) bwd(t - 1);
+                if (tr) c3 = (long long)__builtin_readcyclecounter();
+                if (t + 1 < n_my) fwd(t + 1, A);
+                if (tr) c4 = (long long)__builtin_readcyclecounter();
+            }
+            __syncthreads();
+            if (tr && t >= 2 && t + 2 < n_my) {
+                ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += c4 - c3;
+                ph[4] += (long long)__builtin_readcyclecounter() - c4;
+            }
+        }
+        if (tr && lane == 0 && blockIdx.x < 2048) {
+            long long* o = a.trace + (long long)blockIdx.x * 16;
+            for (int i = 0; i < 5; ++i) o[i] = ph[i];
+            o[5] = n_my > 4 ? n_my - 4 : 0;
+            o[6] = (long long)__builtin_readcyclecounter() - tb;
+            o[7] = (long long)wall_clock64() - wb;
+        }
+    } else {
+        float xv0[4], xv1[4];
+        load_x(0, xv0);
+        __syncthreads();
+        __syncthreads();
+        const bool tr = a.trace != nullptr && wave == 8;
+        long long gph[2] = {0, 0};
+        auto step = [&](int t, float (&xc)[4], float (&xn)[4]) {
+            long long c0 = 0, c1 = 0;
+            if (tr) c0 = (long long)__builtin_readcyclecounter();
+            if (t >= 1 && gt == 0) finish_loss(t - 1);
+            if (t < n_my) {
+                if (t + 1 < n_my) load_x(t + 1, xn);
+                gather(t, xc);
+            }
+            if (tr) c1 = (long long)__builtin_readcyclecounter();
+            __syncthreads();
+            if (tr && t >= 2 && t + 2 < n_my) { gph[0] += c1 - c0; gph[1] += (long long)__builtin_readcyclecounter() - c1; }
+        };
+        for (int t = 0; t <= n_my; t += 2) {
+            step(t, xv0, xv1);
+            if (t + 1 <= n_my) step(t + 1, xv1, xv0);
+        }
+        if (tr && lane == 0 && blockIdx.x < 2048) {
+            long long* o = a.trace + (long long)blockIdx.x * 16;
+            o[8] = gph[0];
+            o[9] = gph[1];
+        }
+    }
+}
+
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
+    if (a.pipe && a.do_backward && a.C == 64 && a.n_rows >= 2 * a.pipe) {
+        constexpr int C = 64;
+        const int lds = (2 * 224 * MN_NKP + 2 * MN_GR * MN_GWP + 2 * 224 * (C / 32) + 8 + (C / 8) * 256 + 13 * 64 * (C / 32)) * 4 + 8 * 32 * C * 4;
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+        hipLaunchKernelGGL((mnist_tail_pipe_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
+        return;
+    }
     const int lds = (224 * MN_NKP + MN_GR * MN_GWP + 224 * (a.C / 32) + 4) * 4;
     if (a.C == 64) hipLaunchKernelGGL((mnist_tail_mfma_kernel<64>), dim3(a.n_rows), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((mnist_tail_mfma_kernel<128>), dim3(a.n_rows), dim3(256), lds, s, a);

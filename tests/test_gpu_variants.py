@@ -69,7 +69,7 @@ def _run(gan, x, z0):
 
 
 BITWISE = {
-    "mnist": [{"persistent": 0}, {"persistent": 2}, {"two_streams": 2, "two_stream_min_rows": 64},
+    "mnist": [{"tail_pipe": 0}, {"tail_pipe": 100}, {"persistent": 0}, {"persistent": 2}, {"two_streams": 2, "two_stream_min_rows": 64},
               {"persistent": 2, "tile.F2": 0, "tile.B3": 0, "tile.B2": 0, "tile.F3": 2},
               {"tile.F2": 1, "tile.B3": 1, "tile.B2": 2, "tile.F1": 1}],
     "celeba": [{"persistent": 0}, {"persistent": 2, "tile.F2": 0, "tile.B3": 1}, {"tail_bwd_persist": 0},
