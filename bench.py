@@ -39,14 +39,16 @@ WORKLOADS = {
 
 
 def traffic_for(workload, kernel, B, R):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_v3_pmc_traffic.json:
-    FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be read from inside this
-    process, so the figure is only reported for the configuration it was collected on (MNIST arch, 2560 rows)."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
-    if kernel is None or not os.path.exists(path) or B * R != 2560:
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_v5_pmc_traffic.json,
+    built by tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be
+    read from inside this process, so the figure is only reported for the configurations it was collected on
+    (MNIST arch at 2560 rows, CelebA at 1280 rows)."""
+    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
+    key = "mnist" if workload in ("mnist", "fmnist") else workload
+    if kernel is None or not os.path.exists(path) or B * R != {"mnist": 2560, "celeba": 1280}.get(key, -1):
         return None
     with open(path) as fh:
-        t = json.load(fh).get("mnist" if workload in ("mnist", "fmnist") else workload, {})
+        t = json.load(fh).get(key, {})
     return t.get(kernel, {}).get("bytes_per_launch")
 
 

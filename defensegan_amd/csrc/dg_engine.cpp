@@ -519,7 +519,9 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.pipe = h->tail_pipe;
         t.trace = h->d_tail_trace;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
-        ProfScope ps(h, s, prof, tail_backward ? "T5fb@mnist_tail_mfma_kernel" : "T5f@mnist_tail_mfma_kernel", (tail_backward ? 4.0 : 2.0) * macs * n_rows);
+        const bool piped = h->tail_mfma && t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
+        ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? "T5fb@mnist_tail_pipe_kernel" : "T5fb@mnist_tail_mfma_kernel",
+                     (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);
     } else {
         dg::CelebaTailArgs t;
@@ -542,12 +544,12 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.bwd_bands = h->tail_bwd_bands;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
-            ProfScope ps(h, s, prof, "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
+            ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
             if (h->tail_mfma) dg::launch_celeba_tail_fwd_mfma(t, s); else dg::launch_celeba_tail_fwd(t, s);
         }
         dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
         if (tail_backward) {
-            ProfScope ps(h, s, prof, "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
+            ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
             if (h->tail_mfma) dg::launch_celeba_tail_bwd_mfma(t, s); else dg::launch_celeba_tail_bwd(t, s);
         }
     }
