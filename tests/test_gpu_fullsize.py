@@ -1,0 +1,55 @@
+"""-m gpu: BASELINE.json's full shapes (configs[2] F-MNIST, configs[3] CelebA; configs[1] MNIST is in test_gpu_mnist.py)
+through size-independent properties of the projection plus an oracle subset (rows are independent, so a subset of
+images is a valid check of the whole batch)."""
+import numpy as np
+import pytest
+
+from defensegan_amd import archs, synth
+from tests.helpers import clean_targets, make_gan
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("arch,wseed,B,nb", [("fmnist", 4321, 256, 3), ("celeba", 1234, 128, 1)])
+def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
+    R, L = 10, 200
+    a = archs.make_arch(arch)
+    P = int(np.prod(a.image_dim))
+    gan, p = make_gan(arch, wseed=wseed, gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, arch, B, seed=41)
+    z0 = synth.make_z(B * R, 128, seed=42)
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    loss = out["loss"].reshape(B, R)
+    assert np.isfinite(out["rec"]).all() and np.isfinite(loss).all()
+    assert out["rec"].min() >= a.in_lo - 1e-6 and out["rec"].max() <= a.in_hi + 1e-6
+    # selection: first argmin of the per-restart losses, reconstruction = G(z_{L-1}) of that row, loss = its MSE to x
+    assert (out["idx"] == loss.argmin(axis=1)).all()
+    rows = np.arange(B) * R + out["idx"]
+    y_sel = np.asarray(gan.generate(out["z"][rows]))
+    np.testing.assert_allclose(out["rec"], y_sel, rtol=0, atol=2e-6)
+    mse_sel = ((out["rec"] - x) ** 2).reshape(B, -1).mean(axis=1)
+    np.testing.assert_allclose(loss.min(axis=1), mse_sel, rtol=2e-4, atol=1e-9)
+    # descent: clean in-range targets at gain 2.0 are the contractive regime
+    gan.rec_iters = 1
+    loss0 = gan.reconstruct(x, z_init_val=z0, return_details=True)["loss"].reshape(B, R)
+    gan.rec_iters = L
+    assert (loss.min(axis=1) < loss0.min(axis=1)).all()
+    assert (loss.min(axis=1) < 0.2 * loss0.min(axis=1)).mean() > 0.9
+    # determinism and independence of the batch composition: the last 7 images alone give the same rows bit for bit
+    sub = gan.reconstruct(x[-7:], z_init_val=z0[-7 * R:], return_details=True)
+    assert np.array_equal(sub["rec"], out["rec"][-7:]) and np.array_equal(sub["loss"], out["loss"][-7 * R:])
+    # oracle (torch-CPU fp32 autograd restatement) on the first nb images.  With these synthetic weights the CelebA loop
+    # at the reference's lr = 10 is CHAOTIC (tools/diag_long_horizon.py: fp32 vs fp64 of the same torch code differ by
+    # 25-50 % in per-restart loss from L = 20 on, the device path sits closer to fp64 than torch-fp32 does), so a
+    # long-horizon value comparison is only meaningful where the loop contracts: lr = 3 for CelebA, lr = 10 for F-MNIST.
+    from oracle import torch_ref as T
+    lr = 3.0 if arch == "celeba" else 10.0
+    gan.rec_lr = lr
+    dev = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
+    t = T.reconstruct(p, x[:nb], z0[:nb * R], R, L, lr=lr, momentum=0.7, arch=arch)
+    mse = ((dev["rec"] - t["rec"]) ** 2).reshape(nb, -1).mean(axis=1)
+    assert (mse < 1e-4).all(), mse                                   # BASELINE: "MSE within 1e-4"
+    gap = np.sort(t["loss"].reshape(nb, R), axis=1)
+    decided = (gap[:, 1] - gap[:, 0]) > 1e-6
+    assert (dev["idx"][decided] == t["idx"][decided]).all()
+    np.testing.assert_allclose(dev["loss"], t["loss"], rtol=0.05, atol=2e-6)
