@@ -694,6 +694,11 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
 // so a third of the padded GEMM of the 32-wide formulation is never issued, and the 20 units split 5/5/5/5 over four
 // waves: w0 = lr2, w1 = lr3, w2 = lr1 + lr5, w3 = lr4 + lr0.  Each unit's P block [32 positions][16] (pitch 17) has its
 // own LDS slot; slot = CE16_BASE[lr] + kh.
+// Measured alternatives to this three-workgroups-per-CU shape (188 us at N = 1280): one persistent workgroup per CU with
+// dedicated GEMM and gather waves and a double-buffered P -- (a) 12 waves, rows staged through a single 48 KB LDS stage
+// (all that fits next to two P buffers): 225 us, the DMA latency sits on every step's critical path; (b) 8 waves, next
+// band's A fragments prefetched into registers by fragment-shaped global loads: 211 us, the single GEMM wave per SIMD
+// spends longer issuing its 16 loads than multiplying.  Both were bit-identical to this kernel and removed.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int CE16_PITCH = 17;
 constexpr int CE16_UNIT = 32 * CE16_PITCH;                 // floats per (row, kh) unit
