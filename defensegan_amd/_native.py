@@ -36,6 +36,13 @@ SYMBOLS = [
     ("dg_profile_reset", _i, [_vp]),
     ("dg_debug_read", _i64, [_vp, _cp, _vp, _i64]),
     ("dg_set_option", _i, [_vp, _cp, _cp]),
+    ("dg_clf_create", _i, [_i, _i, _i, _i, C.POINTER(_vp)]),
+    ("dg_clf_destroy", _i, [_vp]),
+    ("dg_clf_add_layer", _i, [_vp, _i, _i, _i, _i, _i, _i, _i]),
+    ("dg_clf_output_width", _i, [_vp]),
+    ("dg_clf_set_weights", _i, [_vp, _i, _vp, C.POINTER(_i64), _i, _vp, _i64, _i]),
+    ("dg_clf_forward", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    ("dg_eval_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
 ]
 
 _lib: Optional[C.CDLL] = None

@@ -65,13 +65,22 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
             rec = reconstruct(x, seed=seed, first_row=(first_image + start) * rec_rr, **kw)
         else:
             rec = x
-        out = _np(classifier(rec))
-        p = out.argmax(axis=-1) if out.ndim > 1 else out.astype(np.int64)
-        preds.append(p.astype(np.int64))
-        correct += int((p == labels[start:end]).sum())
-        if compute_diffs:
-            xr, rr = _np(x).reshape(end - start, -1), _np(rec).reshape(end - start, -1)
-            diffs.append(((xr - rr) ** 2).mean(axis=1).astype(np.float32))
+        if hasattr(classifier, "eval_batch"):
+            # network_builder.MLP: classifier forward, argmax, correct count and diff_op in one device pass
+            # (dg_eval_batch); only [B] predictions / differences come back
+            ok, p_dev, d_dev = classifier.eval_batch(rec, x if compute_diffs else None, labels[start:end].astype(np.int32))
+            correct += ok
+            preds.append(_np(p_dev).astype(np.int64))
+            if compute_diffs:
+                diffs.append(_np(d_dev).astype(np.float32))
+        else:
+            out = _np(classifier(rec))
+            p = out.argmax(axis=-1) if out.ndim > 1 else out.astype(np.int64)
+            preds.append(p.astype(np.int64))
+            correct += int((p == labels[start:end]).sum())
+            if compute_diffs:
+                xr, rr = _np(x).reshape(end - start, -1), _np(rec).reshape(end - start, -1)
+                diffs.append(((xr - rr) ** 2).mean(axis=1).astype(np.float32))
         if verbose:
             print("[#] Eval batch {}/{}".format(batch, nb_batches))
     preds_all = np.concatenate(preds) if preds else np.zeros(0, np.int64)

@@ -126,8 +126,57 @@ int dg_profile_reset(dg_handle* h);
  * (device pointer, capacity n floats); returns the number of floats copied.  Test hook only. */
 int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
 
-/* Tuning override for experiments: key=value pairs, e.g. "tile.F2=64x128". */
+/*
+ * Tuning / measurement overrides (no reference counterpart; defaults are the measured optimum on MI355X):
+ *   "tile.<op>"        GEMM tile of layer op (F1,F2,F3,F5,B5,B3,B2,B1): 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
+ *   "persistent"       balanced persistent tile lists: 0 never, 1 where measured to pay (default), 2 every layer
+ *   "persist_wgs"      resident workgroups per CU in persistent mode (0 = by the tile's LDS footprint)
+ *   "nsplit"           split-K factor of the Linear backward (default 8)
+ *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
+ *   "tail_mfma"        0 = VALU formulation of the tails (cross-check), 1 = MFMA (default)
+ *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
+ *   "tail_fwd16"       CelebA forward tail: 1 = 16x16x4 kh-aligned (default), 0 = 32x32x2
+ *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel (0 = per-band kernel, "tail_bwd_bands")
+ *   "tail_trace", "tail_dbg", "clk_probe", "xcd_map", "lds_pad"   measurement experiments (tools/)
+ * Every launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py); "nsplit", "tail_fwd16" and
+ * "tail_mfma" change a summation order (agreement to rounding).
+ */
 int dg_set_option(dg_handle* h, const char* key, const char* value);
+
+/* =====================================================================================================
+ * The step after the projection: classifier forward + the per-batch reduction of
+ * model_eval_gan.  Replaces, for evaluation, `model(reconstructed_tensors)` over the cleverhans-style MLP
+ * of /root/reference/utils/network_builder.py:129-331 (models A-F, :333-521) and the `acc_value / cur_preds /
+ * diff_op` fetches of /root/reference/utils/gan_defense.py:91-179, /root/reference/blackbox.py:569-572.
+ * ===================================================================================================== */
+typedef struct dg_clf dg_clf;
+
+#define DG_LAYER_CONV2D 0     /* p0..p5 = output_channels, kernel h, kernel w, stride h, stride w, 1 = "SAME" / 0 = "VALID" */
+#define DG_LAYER_RELU 1
+#define DG_LAYER_LINEAR 2     /* p0 = num_hid                                                                    */
+#define DG_LAYER_FLATTEN 3
+#define DG_LAYER_SOFTMAX 4
+#define DG_LAYER_DROPOUT 5    /* identity: K.learning_phase() is 0 at evaluation (network_builder.py:296-297)     */
+
+/* An empty MLP for NHWC inputs [*, in_h, in_w, in_c] (network_builder.py:129-162). */
+int dg_clf_create(int device, int in_h, int in_w, int in_c, dg_clf** out);
+int dg_clf_destroy(dg_clf* h);
+/* Appends a layer; returns its index (>= 0) or a negative DG_E_* code.  Shapes follow tf.nn.conv2d's SAME / VALID
+ * rules (SAME: out = ceil(in / stride), pad_before = pad_total / 2). */
+int dg_clf_add_layer(dg_clf* h, int kind, int p0, int p1, int p2, int p3, int p4, int p5);
+/* Width of the last layer's output per image (the class count once the model is complete). */
+int dg_clf_output_width(dg_clf* h);
+/* Parameters of a Conv2D (kernels [kh,kw,cin,cout], network_builder.py:213-221) or Linear (W [in,out], :196-203) layer
+ * and its bias; host or device pointers. */
+int dg_clf_set_weights(dg_clf* h, int layer, const float* W, const int64_t* wshape, int wndim, const float* b,
+                       int64_t blen, int is_device);
+/* x [B,in_h,in_w,in_c] -> logits [B,n] (the layer before Softmax, may be NULL) and probs [B,n] (may be NULL; equals the
+ * logits when the model has no Softmax).  Device pointers; asynchronous on `stream`. */
+int dg_clf_forward(dg_clf* h, const float* x, int B, float* logits, float* probs, void* stream);
+/* One evaluation batch: preds[b] = argmax_k model(rec)[b,k] (first maximum), *n_correct += #(preds == labels) (device
+ * int32, caller zeroes it), diffs[b] = mean((orig[b] - rec[b])^2).  labels/preds/diffs/n_correct/orig may be NULL. */
+int dg_eval_batch(dg_clf* h, const float* rec, const float* orig, const int32_t* labels, int B, int32_t* preds,
+                  float* diffs, int32_t* n_correct, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,72 @@
+"""CPU restatement of the reference classifier forward -- TEST INFRASTRUCTURE ONLY, like the rest of
+oracle/: only tests/ may import it; the product path runs the HIP kernels of defensegan_amd/csrc/dg_clf.hip.
+
+Follows /root/reference/utils/network_builder.py:190-331 (Linear: x @ W + b; Conv2D: tf.nn.conv2d(x, kernels[kh,kw,cin,
+cout], strides, padding) + b; ReLU; Flatten = NHWC row-major reshape; Softmax; Dropout = identity at evaluation) and the
+evaluation reduction of /root/reference/utils/gan_defense.py:91-179 (argmax preds, correct count) with diff_op of
+/root/reference/blackbox.py:569-572.  The arithmetic lives in TensorFlow 1.7 (absent, unpinned): tf.nn.conv2d is a
+cross-correlation with SAME = (out = ceil(in/stride), pad_before = pad_total // 2) -- "parity unpinned", pinned here only
+against torch.nn.functional.conv2d with explicit asymmetric padding and hand-computed shapes (tests/test_classifier.py)."""
+import numpy as np
+
+
+def same_padding(n_in: int, k: int, s: int):
+    out = -(-n_in // s)
+    total = max((out - 1) * s + k - n_in, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv2d(x: np.ndarray, K: np.ndarray, b: np.ndarray, strides, padding: str) -> np.ndarray:
+    """x [B,H,W,Cin], K [kh,kw,Cin,Cout] -> [B,Ho,Wo,Cout]."""
+    B, H, W, Cin = x.shape
+    kh, kw, cin, cout = K.shape
+    assert cin == Cin
+    sh, sw = strides
+    if padding == "SAME":
+        Ho, pt, pb = same_padding(H, kh, sh)
+        Wo, pl, pr = same_padding(W, kw, sw)
+    else:
+        Ho, Wo, pt, pb, pl, pr = (H - kh) // sh + 1, (W - kw) // sw + 1, 0, 0, 0, 0
+    xp = np.zeros((B, H + pt + pb, W + pl + pr, Cin), x.dtype)
+    xp[:, pt:pt + H, pl:pl + W, :] = x
+    y = np.zeros((B, Ho, Wo, cout), x.dtype)
+    for a in range(kh):
+        for c in range(kw):
+            patch = xp[:, a:a + (Ho - 1) * sh + 1:sh, c:c + (Wo - 1) * sw + 1:sw, :]
+            y += patch @ K[a, c].astype(x.dtype)
+    return y + b.astype(x.dtype)
+
+
+def forward(layers, params, x: np.ndarray):
+    """layers: list of ("conv", cout, (kh,kw), (sh,sw), padding) | ("relu",) | ("flatten",) | ("linear", n) | ("softmax",) |
+    ("dropout",); params: one (W, b) per conv/linear.  Returns (logits, probs)."""
+    h = x
+    it = iter(params)
+    logits = None
+    for L in layers:
+        kind = L[0]
+        if kind == "conv":
+            W, b = next(it)
+            h = conv2d(h, W, b, L[3], L[4])
+        elif kind == "linear":
+            W, b = next(it)
+            h = h @ W.astype(h.dtype) + b.astype(h.dtype)
+        elif kind == "relu":
+            h = np.maximum(h, 0)
+        elif kind == "flatten":
+            h = h.reshape(len(h), -1)
+        elif kind == "softmax":
+            logits = h
+            e = np.exp(h - h.max(axis=1, keepdims=True))
+            h = e / e.sum(axis=1, keepdims=True)
+        elif kind == "dropout":
+            pass
+        else:
+            raise ValueError(kind)
+    return (logits if logits is not None else h), h
+
+
+def eval_batch(probs: np.ndarray, labels: np.ndarray, rec: np.ndarray, orig: np.ndarray):
+    preds = probs.argmax(axis=1)
+    diffs = ((orig - rec) ** 2).reshape(len(rec), -1).mean(axis=1)
+    return int((preds == labels).sum()), preds, diffs

@@ -1,0 +1,123 @@
+"""SURVEY.md 8f-N2, the step after the projection: classifier forward + model_eval_gan's per-batch reduction.
+CPU: the oracle's conv semantics pinned against torch conv2d with explicit asymmetric SAME padding and hand-computed
+shapes; layer plumbing of the host mirror.  -m gpu: the HIP path (through the C ABI) against the oracle."""
+import numpy as np
+import pytest
+
+from defensegan_amd import network_builder as nb
+from oracle import classifier_oracle as CO
+
+
+def _layers_of(model):
+    out = []
+    for l in model.layers:
+        if isinstance(l, nb.Conv2D):
+            out.append(("conv", l.output_channels, l.kernel_shape, l.strides, l.padding))
+        elif isinstance(l, nb.Linear):
+            out.append(("linear", l.num_hid))
+        else:
+            out.append((l.__class__.__name__.lower(),))
+    return out
+
+
+def test_same_padding_known_answers():
+    # tf.nn.conv2d SAME: out = ceil(in / s), pad_total = max((out-1)*s + k - in, 0), pad_before = pad_total // 2
+    assert CO.same_padding(28, 8, 2) == (14, 3, 3)       # model B/F first layer
+    assert CO.same_padding(28, 5, 1) == (28, 2, 2)       # model A first layer
+    assert CO.same_padding(28, 5, 2) == (14, 1, 2)       # odd total: the extra row goes AFTER
+    assert CO.same_padding(7, 3, 2) == (4, 1, 1)
+    assert CO.same_padding(5, 1, 3) == (2, 0, 0)
+
+
+@pytest.mark.parametrize("H,k,s,pad", [(28, 8, 2, "SAME"), (28, 5, 2, "SAME"), (14, 6, 2, "VALID"), (9, 3, 1, "SAME"), (11, 5, 3, "VALID")])
+def test_oracle_conv_matches_torch(H, k, s, pad):
+    import torch
+    import torch.nn.functional as F
+    rs = np.random.RandomState(H * 10 + k)
+    x = rs.standard_normal((3, H, H + 1, 4))
+    K = rs.standard_normal((k, k, 4, 5))
+    b = rs.standard_normal(5)
+    y = CO.conv2d(x, K, b, (s, s), pad)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2)
+    if pad == "SAME":
+        _, pt, pb = CO.same_padding(H, k, s)
+        _, pl, pr = CO.same_padding(H + 1, k, s)
+        xt = F.pad(xt, (pl, pr, pt, pb))
+    yt = F.conv2d(xt, torch.from_numpy(K).permute(3, 2, 0, 1), torch.from_numpy(b), stride=s).permute(0, 2, 3, 1).numpy()
+    assert y.shape == yt.shape
+    np.testing.assert_allclose(y, yt, rtol=1e-12, atol=1e-12)
+
+
+def test_model_zoo_shapes_and_names():
+    # network_builder.py:333-521: flatten widths of the MNIST models
+    widths = {}
+    for name, fn in nb.MODELS.items():
+        m = fn()
+        shape = (28, 28, 1)
+        for l in m.layers:
+            if isinstance(l, nb.Conv2D):
+                shape = nb.conv_output_shape(shape, l)
+        widths[name] = int(np.prod(shape))
+        assert m.layer_names[-1] == "probs" and m.layer_names[-2] == "logits"
+    assert widths["A"] == 12 * 12 * 64 and widths["B"] == 1 * 1 * 128 and widths["F"] == 128 and widths["C"] == 12 * 12 * 64
+    assert widths["D"] == 784 and widths["E"] == 784
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(nb.MODELS))
+def test_classifier_forward_vs_oracle(name):
+    m = nb.MODELS[name]()
+    params = m.init_like_reference(seed=ord(name))
+    rs = np.random.RandomState(3)
+    params = [(W, rs.uniform(-0.2, 0.2, size=b.shape).astype(np.float32)) for W, b in params]     # exercise the bias path
+    m.set_weights(params)
+    x = rs.uniform(0, 1, size=(7, 28, 28, 1)).astype(np.float32)
+    out = m.fprop(x)
+    lo, po = CO.forward(_layers_of(m), [(W.astype(np.float64), b.astype(np.float64)) for W, b in params], x.astype(np.float64))
+    assert out["logits"].shape == (7, 10)
+    np.testing.assert_allclose(out["logits"], lo, rtol=0, atol=2e-5 * max(1.0, np.abs(lo).max()))
+    np.testing.assert_allclose(out["probs"], po, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["probs"].sum(axis=1), 1.0, atol=1e-6)
+    assert np.array_equal(m(x), out["probs"]) and np.array_equal(m.get_logits(x), out["logits"])
+
+
+@pytest.mark.gpu
+def test_color_input_and_eval_batch_vs_oracle():
+    m = nb.model_a(nb_filters=16, nb_classes=7, input_shape=(None, 64, 64, 3))
+    params = m.init_like_reference(seed=5)
+    rs = np.random.RandomState(9)
+    B = 37
+    rec = rs.uniform(-1, 1, size=(B, 64, 64, 3)).astype(np.float32)
+    orig = np.clip(rec + 0.1 * rs.standard_normal(rec.shape), -1, 1).astype(np.float32)
+    _, po = CO.forward(_layers_of(m), [(W.astype(np.float64), b.astype(np.float64)) for W, b in params], rec.astype(np.float64))
+    labels = po.argmax(axis=1).astype(np.int32)
+    labels[::5] = (labels[::5] + 1) % 7                      # some wrong on purpose
+    n_ok, preds, diffs = m.eval_batch(rec, orig, labels)
+    want_ok, want_preds, want_diffs = CO.eval_batch(po, labels, rec.astype(np.float64), orig.astype(np.float64))
+    assert n_ok == want_ok and np.array_equal(preds.cpu().numpy(), want_preds)
+    np.testing.assert_allclose(diffs.cpu().numpy(), want_diffs, rtol=2e-6)
+    n2, p2, d2 = m.eval_batch(rec)                           # no labels / originals
+    assert n2 == 0 and d2 is None and np.array_equal(p2.cpu().numpy(), want_preds)
+
+
+@pytest.mark.gpu
+def test_defended_evaluation_end_to_end_on_device():
+    """cfg-5 pipeline shape on one rank: x -> Defense-GAN projection -> classifier -> (accuracy, roc_info), ragged batches,
+    through the same model_eval_gan harness the reference drives (gan_defense.py:113-179)."""
+    from defensegan_amd import gan_defense
+    from tests.helpers import clean_targets, make_gan
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=3, rec_iters=20)
+    x, _ = clean_targets(p, "mnist", 23, seed=4)
+    clf = nb.model_f(nb_filters=8)
+    clf.init_like_reference(seed=1)
+    labels = clf(x).argmax(axis=1)                             # the undefended predictions as "ground truth"
+    correct, n, roc = gan_defense.model_eval_gan(gan.reconstruct, clf, x, labels, batch_size=10, rec_rr=3, seed=2)
+    assert n == 23 and roc[0].shape == roc[1].shape == roc[2].shape == (23,)
+    assert correct == int((roc[1] == labels).sum()) and (roc[2] >= 0).all() and np.isfinite(roc[2]).all()
+    # clean in-range targets are reconstructed almost exactly, so the defended classifier agrees with the undefended one
+    assert correct >= 21
+    # the classifier wrapped around the projection (whitebox.py:185 add_rec_model) gives the same predictions
+    clf.add_rec_model(gan, None, 23)
+    out = clf.fprop(x)
+    assert "reconstruction" in out and out["reconstruction"].shape == x.shape
+    assert (out["probs"].argmax(axis=1) == labels).mean() > 0.9
