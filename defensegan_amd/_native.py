@@ -43,6 +43,8 @@ SYMBOLS = [
     ("dg_clf_set_weights", _i, [_vp, _i, _vp, C.POINTER(_i64), _i, _vp, _i64, _i]),
     ("dg_clf_forward", _i, [_vp, _vp, _i, _vp, _vp, _vp]),
     ("dg_eval_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("dg_clf_input_gradient", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    ("dg_fgsm", _i, [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp]),
 ]
 
 _lib: Optional[C.CDLL] = None

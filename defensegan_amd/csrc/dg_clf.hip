@@ -147,6 +147,97 @@ __global__ __launch_bounds__(256) void clf_eval_kernel(const float* __restrict__
     }
 }
 
+// ---- backward to the input (FGSM) ----------------------------------------------------------------------
+// g = dCE/dlogits = softmax(logits) - onehot(label); label = the model's own first argmax when labels == nullptr (what
+// cleverhans' FastGradientMethod does when no y is given, to avoid label leaking).
+__global__ __launch_bounds__(64) void clf_ce_grad_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                          float* __restrict__ g, int B, int n) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* r = logits + (long long)b * n;
+    float m = r[0];
+    int best = 0;
+    for (int k = 1; k < n; ++k)
+        if (r[k] > m) { m = r[k]; best = k; }
+    const int y = labels ? labels[b] : best;
+    float s = 0.f;
+    for (int k = 0; k < n; ++k) s += expf(r[k] - m);
+    const float inv = 1.0f / s;
+    for (int k = 0; k < n; ++k) g[(long long)b * n + k] = expf(r[k] - m) * inv - (k == y ? 1.0f : 0.0f);
+}
+
+// dx[b, i] = sum_o gm[b, o] * W[i, o], gm = g masked by the layer's own ReLU (out > 0) when it was fused
+__global__ __launch_bounds__(256) void clf_linear_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                              const float* __restrict__ W, float* __restrict__ dx, long long total,
+                                                              int n_in, int n_out, int relu) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int i = (int)(t % n_in);
+    const long long b = t / n_in;
+    const float* gb = g + b * n_out;
+    const float* ob = out + b * n_out;
+    const float* wr = W + (long long)i * n_out;
+    float acc = 0.f;
+    for (int o = 0; o < n_out; ++o) {
+        const float gv = (relu && !(ob[o] > 0.f)) ? 0.f : gb[o];
+        acc = __builtin_fmaf(gv, wr[o], acc);
+    }
+    dx[t] = acc;
+}
+
+// dx[b, yi, xi, ci] = sum over (a, c) with yo*sh + a - pad_t == yi, xo*sw + c - pad_l == xi, and co of gm[b,yo,xo,co] * K[a,c,ci,co]
+__global__ __launch_bounds__(256) void clf_conv2d_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                              const float* __restrict__ K, float* __restrict__ dx, long long total,
+                                                              int ih, int iw, int ic, int oh, int ow, int oc, int kh, int kw, int sh,
+                                                              int sw, int pad_t, int pad_l, int relu) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int ci = (int)(t % ic);
+    long long r = t / ic;
+    const int xi = (int)(r % iw);
+    r /= iw;
+    const int yi = (int)(r % ih);
+    const long long b = r / ih;
+    float acc = 0.f;
+    for (int a = 0; a < kh; ++a) {
+        const int ty = yi + pad_t - a;
+        if (ty < 0 || ty % sh) continue;
+        const int yo = ty / sh;
+        if (yo >= oh) continue;
+        for (int c = 0; c < kw; ++c) {
+            const int tx = xi + pad_l - c;
+            if (tx < 0 || tx % sw) continue;
+            const int xo = tx / sw;
+            if (xo >= ow) continue;
+            const long long obase = ((b * oh + yo) * ow + xo) * oc;
+            const float* kp = K + ((long long)(a * kw + c) * ic + ci) * oc;
+            for (int co = 0; co < oc; ++co) {
+                const float gv = (relu && !(out[obase + co] > 0.f)) ? 0.f : g[obase + co];
+                acc = __builtin_fmaf(gv, kp[co], acc);
+            }
+        }
+    }
+    dx[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void clf_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ out,
+                                                            float* __restrict__ dx, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) dx[i] = out[i] > 0.f ? g[i] : 0.f;
+}
+
+// x_adv = clip(x + eps * sign(grad), lo, hi)   (cleverhans fgm with ord = inf; sign(0) = 0 as tf.sign)
+__global__ __launch_bounds__(256) void clf_fgsm_kernel(const float* __restrict__ x, const float* __restrict__ grad,
+                                                        float* __restrict__ xadv, long long total, float eps, float lo, float hi) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float gsign = grad[i] > 0.f ? 1.f : (grad[i] < 0.f ? -1.f : 0.f);
+    float v = x[i] + eps * gsign;
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
+    xadv[i] = v;
+}
+
 }  // namespace
 
 struct dg_clf {
@@ -159,6 +250,10 @@ struct dg_clf {
     float* buf[2] = {nullptr, nullptr};
     size_t buf_floats = 0;
     float* scores = nullptr;                  // [B, n_out] scratch of dg_eval_batch
+    std::vector<float*> acts;                 // per-layer outputs kept by the gradient path
+    std::vector<size_t> acts_floats;
+    float* gbuf[2] = {nullptr, nullptr};      // gradient ping-pong
+    size_t gbuf_floats = 0;
     size_t scores_floats = 0;
     int n_out = 0;
 };
@@ -189,6 +284,10 @@ int dg_clf_destroy(dg_clf* h) {
     for (float* p : h->buf)
         if (p) (void)hipFree(p);
     if (h->scores) (void)hipFree(h->scores);
+    for (float* p : h->acts)
+        if (p) (void)hipFree(p);
+    for (float* p : h->gbuf)
+        if (p) (void)hipFree(p);
     delete h;
     return DG_OK;
 }
@@ -282,7 +381,7 @@ int dg_clf_set_weights(dg_clf* h, int layer, const float* W, const int64_t* wsha
     return DG_OK;
 }
 
-static int clf_run(dg_clf* h, const float* x, int B, float* logits, float* probs, hipStream_t s) {
+static int clf_run(dg_clf* h, const float* x, int B, float* logits, float* probs, hipStream_t s, bool keep = false) {
     for (size_t j = 0; j < h->layers.size(); ++j)
         if ((h->layers[j].kind == L_CONV || h->layers[j].kind == L_LINEAR) && !h->layers[j].have_w)
             return fail(DG_E_STATE, "classifier layer %d has no weights", (int)j);
@@ -311,6 +410,16 @@ static int clf_run(dg_clf* h, const float* x, int B, float* logits, float* probs
         if (l.skip || l.kind == L_SOFTMAX) continue;
         const long long total = (long long)B * l.oh * l.ow * l.oc;
         float* out = (j == last_param && logits) ? logits : h->buf[which];
+        if (keep) {                                      // the gradient path needs every layer's output afterwards
+            if (h->acts.size() < h->layers.size()) { h->acts.resize(h->layers.size(), nullptr); h->acts_floats.resize(h->layers.size(), 0); }
+            if ((size_t)total > h->acts_floats[j]) {
+                if (h->acts[j]) (void)hipFree(h->acts[j]);
+                h->acts[j] = nullptr;
+                CLF_TRY(hipMalloc(&h->acts[j], (size_t)total * sizeof(float)));
+                h->acts_floats[j] = (size_t)total;
+            }
+            out = h->acts[j];
+        }
         const unsigned grid = (unsigned)((total + 255) / 256);
         if (l.kind == L_CONV)
             hipLaunchKernelGGL(clf_conv2d_kernel, dim3(grid), dim3(256), 0, s, cur, l.W, l.b, out, total, l.ih, l.iw, l.ic, l.oh,
@@ -357,6 +466,73 @@ int dg_eval_batch(dg_clf* h, const float* rec, const float* orig, const int32_t*
     if (rc) return rc;
     const int P = h->in_h * h->in_w * h->in_c;
     hipLaunchKernelGGL(clf_eval_kernel, dim3(B), dim3(256), 0, s, scratch, ncls, rec, orig, P, labels, preds, diffs, n_correct);
+    CLF_TRY(hipGetLastError());
+    return DG_OK;
+}
+
+// d(sum_b CE(softmax(logits_b), y_b))/dx for x [B,H,W,C]; y = labels or, when NULL, the model's own prediction.
+static int clf_input_gradient(dg_clf* h, const float* x, const int32_t* labels, int B, float** grad_out, hipStream_t s) {
+    int rc = clf_run(h, x, B, nullptr, nullptr, s, /*keep=*/true);
+    if (rc) return rc;
+    size_t need = (size_t)B * h->in_h * h->in_w * h->in_c;
+    for (const auto& l : h->layers) need = std::max(need, (size_t)B * l.oh * l.ow * l.oc);
+    if (need > h->gbuf_floats) {
+        for (float*& p : h->gbuf) {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+            CLF_TRY(hipMalloc(&p, need * sizeof(float)));
+        }
+        h->gbuf_floats = need;
+    }
+    int last = -1;
+    for (int j = 0; j < (int)h->layers.size(); ++j)
+        if (!h->layers[j].skip && h->layers[j].kind != L_SOFTMAX) last = j;
+    const int n = h->layers[last].oh * h->layers[last].ow * h->layers[last].oc;
+    int which = 0;
+    float* g = h->gbuf[which];
+    hipLaunchKernelGGL(clf_ce_grad_kernel, dim3((B + 63) / 64), dim3(64), 0, s, h->acts[last], labels, g, B, n);
+    for (int j = last; j >= 0; --j) {
+        const ClfLayer& l = h->layers[j];
+        if (l.skip || l.kind == L_SOFTMAX) continue;
+        const long long total = (long long)B * l.ih * l.iw * l.ic;
+        float* dx = h->gbuf[which ^ 1];
+        const unsigned grid = (unsigned)((total + 255) / 256);
+        if (l.kind == L_LINEAR)
+            hipLaunchKernelGGL(clf_linear_bwd_kernel, dim3(grid), dim3(256), 0, s, g, h->acts[j], l.W, dx, total, l.cin, l.cout,
+                               l.fused_relu ? 1 : 0);
+        else if (l.kind == L_CONV)
+            hipLaunchKernelGGL(clf_conv2d_bwd_kernel, dim3(grid), dim3(256), 0, s, g, h->acts[j], l.W, dx, total, l.ih, l.iw, l.ic,
+                               l.oh, l.ow, l.oc, l.kh, l.kw, l.sh, l.sw, l.pad_t, l.pad_l, l.fused_relu ? 1 : 0);
+        else
+            hipLaunchKernelGGL(clf_relu_bwd_kernel, dim3(grid), dim3(256), 0, s, g, h->acts[j], dx, total);
+        which ^= 1;
+        g = dx;
+    }
+    CLF_TRY(hipGetLastError());
+    *grad_out = g;
+    return DG_OK;
+}
+
+int dg_clf_input_gradient(dg_clf* h, const float* x, const int32_t* labels, int B, float* grad, void* stream) {
+    if (!h || !x || !grad || B <= 0) return fail(DG_E_INVALID, "dg_clf_input_gradient: bad argument");
+    CLF_TRY(hipSetDevice(h->device));
+    float* g = nullptr;
+    int rc = clf_input_gradient(h, x, labels, B, &g, (hipStream_t)stream);
+    if (rc) return rc;
+    CLF_TRY(hipMemcpyAsync(grad, g, (size_t)B * h->in_h * h->in_w * h->in_c * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DG_OK;
+}
+
+int dg_fgsm(dg_clf* h, const float* x, const int32_t* labels, int B, float eps, float clip_min, float clip_max, float* x_adv,
+            void* stream) {
+    if (!h || !x || !x_adv || B <= 0) return fail(DG_E_INVALID, "dg_fgsm: bad argument");
+    CLF_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    float* g = nullptr;
+    int rc = clf_input_gradient(h, x, labels, B, &g, s);
+    if (rc) return rc;
+    const long long total = (long long)B * h->in_h * h->in_w * h->in_c;
+    hipLaunchKernelGGL(clf_fgsm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, g, x_adv, total, eps, clip_min, clip_max);
     CLF_TRY(hipGetLastError());
     return DG_OK;
 }

@@ -296,3 +296,60 @@ def model_z(nb_filters=32, nb_classes=10, input_shape=(None, 28, 28, 1), rec_mod
 
 MODELS = {"A": model_a, "B": model_b, "C": model_c, "D": model_d, "E": model_e, "F": model_f, "Y": model_y, "Q": model_q,
           "Z": model_z}
+
+
+# ---------------------------------------------------------------------- the step BEFORE the path: FGSM
+def _mlp_input_gradient(self, x, labels=None):
+    """d(sum_b CE(softmax(logits_b), y_b))/dx on the device; y = ``labels`` (class indices) or the model's own prediction."""
+    import torch
+    self._ensure()
+    if not self._weights_set:
+        raise _native.NativeError("classifier weights not set")
+    was_numpy = isinstance(x, np.ndarray)
+    dev = torch.device("cuda", self._device)
+    t = (torch.from_numpy(np.ascontiguousarray(x, np.float32)) if was_numpy else x).to(device=dev, dtype=torch.float32).contiguous()
+    lab = None
+    if labels is not None:
+        lab = (torch.from_numpy(np.ascontiguousarray(labels)) if isinstance(labels, np.ndarray) else labels).to(device=dev, dtype=torch.int32).contiguous()
+    g = torch.empty_like(t)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        _native.check(_native.load().dg_clf_input_gradient(self._handle, t.data_ptr(), lab.data_ptr() if lab is not None else None,
+                                                           int(t.shape[0]), g.data_ptr(), stream))
+    return g.cpu().numpy() if was_numpy else g
+
+
+MLP.input_gradient = _mlp_input_gradient
+
+
+class FastGradientMethod(object):
+    """The cleverhans attack object the reference instantiates (whitebox.py:198-200, blackbox.py:530-534), ord = inf only:
+    ``adv = clip(x + eps * sign(grad_x CE(model(x), y)), clip_min, clip_max)``; without ``y`` the model's own prediction is
+    the label (cleverhans' default).  ``sess`` / ``back`` are accepted for signature compatibility and ignored."""
+
+    def __init__(self, model: MLP, back="tf", sess=None):
+        self.model = model
+
+    def generate(self, x, eps=0.3, ord=np.inf, y=None, clip_min=None, clip_max=None, **kwargs):
+        import torch
+        if ord not in (np.inf, "inf", float("inf")):
+            raise NotImplementedError("only ord = inf (the reference's setting) is implemented")
+        m = self.model
+        m._ensure()
+        was_numpy = isinstance(x, np.ndarray)
+        dev = torch.device("cuda", m._device)
+        t = (torch.from_numpy(np.ascontiguousarray(x, np.float32)) if was_numpy else x).to(device=dev, dtype=torch.float32).contiguous()
+        lab = None
+        if y is not None:
+            yy = y if isinstance(y, np.ndarray) else y.detach().cpu().numpy()
+            if yy.ndim > 1:
+                yy = yy.argmax(axis=-1)                            # one-hot labels as cleverhans takes them
+            lab = torch.from_numpy(np.ascontiguousarray(yy)).to(device=dev, dtype=torch.int32)
+        out = torch.empty_like(t)
+        lo = float("-inf") if clip_min is None else float(clip_min)
+        hi = float("inf") if clip_max is None else float(clip_max)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _native.check(_native.load().dg_fgsm(m._handle, t.data_ptr(), lab.data_ptr() if lab is not None else None,
+                                                 int(t.shape[0]), float(eps), lo, hi, out.data_ptr(), stream))
+        return out.cpu().numpy() if was_numpy else out

@@ -178,6 +178,17 @@ int dg_clf_forward(dg_clf* h, const float* x, int B, float* logits, float* probs
 int dg_eval_batch(dg_clf* h, const float* rec, const float* orig, const int32_t* labels, int B, int32_t* preds,
                   float* diffs, int32_t* n_correct, void* stream);
 
+/*
+ * The step before the path: the FGSM inputs of /root/reference/whitebox.py:198-210 and
+ * /root/reference/blackbox.py:521-534 (cleverhans FastGradientMethod, ord = inf; cleverhans itself is an un-pinned,
+ * empty submodule of the reference, its published fgm is restated):
+ *     x_adv = clip(x + eps * sign(d CE(softmax(logits(x)), y) / dx), clip_min, clip_max)
+ * y = labels, or the model's own prediction when labels == NULL (cleverhans' default, avoids label leaking).
+ */
+int dg_clf_input_gradient(dg_clf* h, const float* x, const int32_t* labels, int B, float* grad, void* stream);
+int dg_fgsm(dg_clf* h, const float* x, const int32_t* labels, int B, float eps, float clip_min, float clip_max,
+            float* x_adv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,68 @@ def eval_batch(probs: np.ndarray, labels: np.ndarray, rec: np.ndarray, orig: np.
     preds = probs.argmax(axis=1)
     diffs = ((orig - rec) ** 2).reshape(len(rec), -1).mean(axis=1)
     return int((preds == labels).sum()), preds, diffs
+
+
+# ---------------------------------------------------------------------------------------------- input gradient / FGSM
+def conv2d_backward_input(g: np.ndarray, K: np.ndarray, x_shape, strides, padding: str) -> np.ndarray:
+    """d/dx of sum(g * conv2d(x, K)): scatter form of the same index map as conv2d above."""
+    B, H, W, Cin = x_shape
+    kh, kw, _, cout = K.shape
+    sh, sw = strides
+    if padding == "SAME":
+        Ho, pt, pb = same_padding(H, kh, sh)
+        Wo, pl, pr = same_padding(W, kw, sw)
+    else:
+        Ho, Wo, pt, pb, pl, pr = (H - kh) // sh + 1, (W - kw) // sw + 1, 0, 0, 0, 0
+    dxp = np.zeros((B, H + pt + pb, W + pl + pr, Cin), g.dtype)
+    for a in range(kh):
+        for c in range(kw):
+            dxp[:, a:a + (Ho - 1) * sh + 1:sh, c:c + (Wo - 1) * sw + 1:sw, :] += g @ K[a, c].astype(g.dtype).T
+    return dxp[:, pt:pt + H, pl:pl + W, :]
+
+
+def input_gradient(layers, params, x: np.ndarray, labels=None):
+    """d(sum_b CE(softmax(logits_b), y_b))/dx; y = labels or the model's own first argmax (cleverhans fgm default)."""
+    acts = [x]
+    it = iter(params)
+    used = []
+    for L in layers:
+        h = acts[-1]
+        kind = L[0]
+        if kind == "conv":
+            W, b = next(it); used.append((W, b)); h = conv2d(h, W, b, L[3], L[4])
+        elif kind == "linear":
+            W, b = next(it); used.append((W, b)); h = h @ W.astype(h.dtype) + b.astype(h.dtype)
+        elif kind == "relu":
+            h = np.maximum(h, 0)
+        elif kind == "flatten":
+            h = h.reshape(len(h), -1)
+        elif kind == "softmax":
+            break
+        acts.append(h)
+    logits = acts[-1]
+    y = np.asarray(labels) if labels is not None else logits.argmax(axis=1)
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    g = e / e.sum(axis=1, keepdims=True)
+    g[np.arange(len(g)), y] -= 1.0
+    body = [L for L in layers if L[0] != "softmax"]
+    pi = len(used)
+    for li in range(len(body) - 1, -1, -1):
+        L, xin, out = body[li], acts[li], acts[li + 1]
+        kind = L[0]
+        if kind == "conv":
+            pi -= 1
+            g = conv2d_backward_input(g, used[pi][0], xin.shape, L[3], L[4])
+        elif kind == "linear":
+            pi -= 1
+            g = g @ used[pi][0].astype(g.dtype).T
+        elif kind == "relu":
+            g = g * (out > 0)
+        elif kind == "flatten":
+            g = g.reshape(xin.shape)
+    return g
+
+
+def fgsm(layers, params, x, eps, clip_min, clip_max, labels=None):
+    g = input_gradient(layers, params, x, labels)
+    return np.clip(x + eps * np.sign(g), clip_min, clip_max), g

@@ -121,3 +121,71 @@ def test_defended_evaluation_end_to_end_on_device():
     out = clf.fprop(x)
     assert "reconstruction" in out and out["reconstruction"].shape == x.shape
     assert (out["probs"].argmax(axis=1) == labels).mean() > 0.9
+
+
+# ------------------------------------------------------------------------------------------------ N3: FGSM
+def test_oracle_input_gradient_finite_differences():
+    m = nb.MLP([nb.Conv2D(3, (3, 3), (2, 2), "SAME"), nb.ReLU(), nb.Conv2D(4, (2, 2), (1, 1), "VALID"), nb.ReLU(), nb.Flatten(),
+                nb.Linear(6), nb.ReLU(), nb.Dropout(0.5), nb.Linear(5), nb.Softmax()], (None, 7, 6, 2))
+    layers = _layers_of(m)
+    rs = np.random.RandomState(0)
+    params = [(rs.standard_normal((3, 3, 2, 3)), rs.standard_normal(3)), (rs.standard_normal((2, 2, 3, 4)), rs.standard_normal(4)),
+              (rs.standard_normal((4 * 3 * 2, 6)) if False else rs.standard_normal((24, 6)), rs.standard_normal(6)),
+              (rs.standard_normal((6, 5)), rs.standard_normal(5))]
+    x = rs.standard_normal((2, 7, 6, 2))
+    lo, _ = CO.forward(layers, params, x)
+    assert lo.shape == (2, 5)
+    labels = np.array([1, 3])
+
+    def loss(xx):
+        l, p = CO.forward(layers, params, xx)
+        return -np.log(p[np.arange(2), labels]).sum()
+    g = CO.input_gradient(layers, params, x, labels)
+    num = np.zeros_like(x)
+    for idx in np.ndindex(*x.shape):
+        d = np.zeros_like(x); d[idx] = 1e-6
+        num[idx] = (loss(x + d) - loss(x - d)) / 2e-6
+    np.testing.assert_allclose(g, num, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["A", "B", "E"])
+def test_input_gradient_and_fgsm_vs_oracle(name):
+    m = nb.MODELS[name]()
+    params = m.init_like_reference(seed=11)
+    rs = np.random.RandomState(12)
+    params = [(W, rs.uniform(-0.1, 0.1, size=b.shape).astype(np.float32)) for W, b in params]
+    m.set_weights(params)
+    x = rs.uniform(0, 1, size=(6, 28, 28, 1)).astype(np.float32)
+    labels = rs.randint(0, 10, size=6).astype(np.int32)
+    p64 = [(W.astype(np.float64), b.astype(np.float64)) for W, b in params]
+    for lab in (labels, None):
+        g = m.input_gradient(x, lab)
+        xo, go = CO.fgsm(_layers_of(m), p64, x.astype(np.float64), 0.3, 0.0, 1.0, lab)
+        np.testing.assert_allclose(g, go, rtol=0, atol=2e-5 * np.abs(go).max())
+        xa = nb.FastGradientMethod(m).generate(x, eps=0.3, clip_min=0.0, clip_max=1.0, y=lab)
+        assert xa.min() >= 0.0 and xa.max() <= 1.0 and np.abs(xa - x).max() <= 0.3 + 1e-6
+        decided = np.abs(go) > 1e-4 * np.abs(go).max()           # sign() is only comparable away from 0
+        assert decided.mean() > 0.5
+        np.testing.assert_allclose(xa[decided], xo[decided], rtol=0, atol=1e-6)
+    # one-hot labels as cleverhans takes them
+    onehot = np.eye(10, dtype=np.float32)[labels]
+    assert np.array_equal(nb.FastGradientMethod(m).generate(x, eps=0.3, clip_min=0.0, clip_max=1.0, y=onehot),
+                          nb.FastGradientMethod(m).generate(x, eps=0.3, clip_min=0.0, clip_max=1.0, y=labels))
+
+
+@pytest.mark.gpu
+def test_attack_then_defend_pipeline_runs_on_device():
+    """blackbox.py:521-575 in miniature: FGSM inputs from a substitute, projection, black-box classifier, reduction."""
+    from defensegan_amd import gan_defense
+    from tests.helpers import clean_targets, make_gan
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=2, rec_iters=10)
+    x, _ = clean_targets(p, "mnist", 12, seed=6)
+    sub, bbox = nb.model_e(), nb.model_b(nb_filters=8)
+    sub.init_like_reference(seed=3)
+    bbox.init_like_reference(seed=4)
+    x_adv = nb.FastGradientMethod(sub).generate(x, eps=0.3, clip_min=0.0, clip_max=1.0)
+    assert x_adv.shape == x.shape and 0.05 < np.abs(x_adv - x).max() <= 0.3 + 1e-6
+    labels = bbox(x).argmax(axis=1)
+    c, n, roc = gan_defense.model_eval_gan(gan.reconstruct, bbox, x_adv, labels, batch_size=5, rec_rr=2, seed=1)
+    assert n == 12 and 0 <= c <= 12 and (roc[2] > 0).all()       # adversarial inputs are off the generator's range
