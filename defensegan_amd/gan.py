@@ -170,6 +170,25 @@ class DefenseGANBase(object):
             raise ValueError("%s lacks %s" % (ckpt_path, ", ".join(missing)))
         return True
 
+    def save_ds(self, splits, root: str = "data/cache", test_again: bool = False):
+        """Counterpart of ``save_ds`` (gan.py:604-646): ``<root>/<dataset>_pkl/<split>/feats.pkl`` holding two consecutive
+        pickles, the transformed images ``[n,H,W,C]`` (``input_transform`` of the raw [0,255] data) and the targets.
+        ``splits``: {'train'|'dev'|'test': (raw images, targets)}.  Protocol 2, so the Python-2 reference can read it."""
+        import pickle
+        out = {}
+        for split, (images, targets) in splits.items():
+            out_dir = os.path.join(root, "{}_pkl".format(self.dataset_name or self.arch_name), split)
+            os.makedirs(out_dir, exist_ok=True)
+            path = os.path.join(out_dir, "feats.pkl")
+            out[split] = path
+            if os.path.exists(path) and not test_again:
+                continue
+            x = self.input_transform(np.asarray(images, np.float32)).reshape([-1] + list(self.image_dim)).astype(np.float32)
+            with open(path, "wb") as f:
+                pickle.dump(x, f, protocol=2)
+                pickle.dump(np.asarray(targets), f, protocol=2)
+        return out
+
     # ------------------------------------------------------------------ the hot path
     def input_transform(self, X):
         """[0,255] -> generator range: /255 for MNIST / F-MNIST (gan.py:684-685, 697-698),
@@ -265,6 +284,17 @@ class DefenseGANBase(object):
             os.makedirs(pk_dir, exist_ok=True)
             n = len(images) if max_num <= 0 else min(len(images), max_num)
             recs = []
+            # a whole-split ``feats.pkl`` (gan.py:484-496) short-cuts the per-image pickles when present
+            feats_path = os.path.join(out_dir, "feats.pkl")
+            if os.path.exists(feats_path) and not test_again:
+                try:
+                    with open(feats_path, "rb") as f:
+                        allr = np.asarray(pickle.load(f, encoding="latin1"), np.float32).reshape([-1] + list(self.image_dim))
+                    if len(allr) >= n:
+                        rets[split] = [allr[:n], np.asarray(targets[:n]), np.asarray(images[:n]).reshape([-1] + list(self.image_dim))]
+                        continue
+                except Exception:
+                    pass
             for start in range(0, n, bs):
                 end = min(n, start + bs)
                 paths = [os.path.join(pk_dir, "rec_{:07d}_l{}.pkl".format(i, targets[i])) for i in range(start, end)]

@@ -152,6 +152,21 @@ def test_reconstruct_dataset_cache_layout(tmp_path):
     again = gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)       # served from the cache
     assert len(calls) == n_before
     np.testing.assert_allclose(again["test"][0], x * 0.5)
+    # a whole-split feats.pkl (gan.py:484-496) takes precedence over the per-image pickles
+    feats = tmp_path / "recs_rr2_lr10.00000_iters5" / "test" / "feats.pkl"
+    with open(feats, "wb") as f:
+        pickle.dump(x * 0.25, f, protocol=2)
+    np.testing.assert_allclose(gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)["test"][0], x * 0.25)
+    assert len(calls) == n_before
+    feats.unlink()
+    # save_ds (gan.py:604-646): transformed images + targets as two consecutive pickles
+    raw = (x * 255.0).astype(np.float32)
+    paths = gan.save_ds({"dev": (raw, y)}, root=str(tmp_path / "cache"))
+    assert paths["dev"].endswith("mnist_pkl/dev/feats.pkl")
+    with open(paths["dev"], "rb") as f:
+        a, b = pickle.load(f), pickle.load(f)
+    np.testing.assert_allclose(a, x, rtol=1e-6)
+    assert a.shape == (7, 28, 28, 1) and np.array_equal(b, y)
     # the classifier-side wrapper forwards to reconstruct with the reference's arguments
     layer = ReconstructionLayer(gan, None, [None, 28, 28, 1], 3)
     np.testing.assert_allclose(layer.fprop(x[:2]), x[:2] * 0.5)
