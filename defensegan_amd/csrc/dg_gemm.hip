@@ -166,20 +166,23 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 
     // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk (instead of
     // DMA for a next chunk), so their HBM/L2 latency hides under that chunk's MFMAs.
-    float oldv[TM][TN][16];
+    // Store layout of the epilogue (see below): pass p of tile (i, j) covers rows p*8 + (lane >> 3), columns 4*(lane & 7)..+3.
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    f32x4 oldv[TM][TN][4];
     auto prefetch_mask = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = pe_n0 + wn * (BN / 2) + j * 32 + frow;
+            const int col = pe_n0 + wn * (BN / 2) + j * 32 + ec;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+                const int row0 = m0 + wm * (BM / 2) + i * 32 + er;
                 const float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
                 const unsigned rs = (unsigned)g.out_rowstride;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int dr = (e & 3) + 8 * (e >> 2);
-                    oldv[i][j][e] = (row0 + dr < g.n_rows) ? obase[(unsigned)dr * rs] : 0.f;
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (row0 + p * 8 < g.n_rows) v = *reinterpret_cast<const f32x4*>(obase + (unsigned)(p * 8) * rs);
+                    oldv[i][j][p] = v;
                 }
             }
         }
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) oldv[i][j][e] = 0.f;
+                for (int p = 0; p < 4; ++p) oldv[i][j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     if (nchunks > 0) {                         // zero-tap positions (BN mode: cropped outputs) just store zeros
         next_chunk_offsets();
@@ -260,24 +263,34 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         long long* t = g.trace + (long long)blockIdx.x * 4;
         t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
     }
-    // ---- epilogue: D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) --------------
-    // Each store instruction writes two 128-B row segments (32 consecutive channels x 2 rows).
+    // ---- epilogue -------------------------------------------------------------------------------------------------
+    // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each 32x32 accumulator tile is transposed through
+    // this wave's 4 KB slice of the stage buffer the last chunk did NOT use (nobody reads it any more: the barrier at the
+    // start of the last chunk retired its readers and the last chunk issues no DMA), so that a lane owns 4 consecutive
+    // channels of one row: 4 b128 stores (and, for ReluGrad, 4 b128 gate loads) per tile instead of 16 dword ones.
+    float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = pe_n0 + wn * (BN / 2) + j * 32 + frow;
-        float bv = 0.f;
-        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = g.bias[col];
+        const int col = pe_n0 + wn * (BN / 2) + j * 32 + ec;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int row0 = m0 + wm * (BM / 2) + i * 32 + 4 * fh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[i][j][e];
+            const int row0 = m0 + wm * (BM / 2) + i * 32 + er;
             float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int dr = (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] + bv;
-                if constexpr (MODE == EPI_BIAS_RELU) v = v > 0.f ? v : 0.f;
-                if constexpr (MODE == EPI_MASK) v = oldv[i][j][e] > 0.f ? v : 0.f;
-                if (row0 + dr < g.n_rows) obase[(long long)dr * g.out_rowstride] = v;
+            for (int p = 0; p < 4; ++p) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = v[q] + bv[q];
+                    if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
+                    if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
+                    v[q] = t;
+                }
+                if (row0 + p * 8 < g.n_rows) *reinterpret_cast<f32x4*>(obase + (long long)(p * 8) * g.out_rowstride) = v;
             }
         }
     }
