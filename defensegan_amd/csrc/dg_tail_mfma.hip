@@ -415,14 +415,24 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
         const int oh = qq / 14, ow = qq - oh * 14;
         f32x16 acc[C / 32];
         tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, (2 * oh) * MN_GWP + 2 * ow, qvalid, sWb, acc, lane);
+        // masked results go through this wave's tile of the P buffer of the same parity (free until the forward GEMM later
+        // in this step rewrites it) so that a lane owns 4 consecutive channels: 4 b128 row stores per 32-channel block
+        // instead of 16 dword ones
+        float* tb = sP + (k & 1) * PSZ + tile * 32 * MN_NKP;         // >= 32 x 32 floats
+        const int er = lane >> 3, ec = (lane & 7) * 4;
 #pragma unroll
         for (int u = 0; u < C / 32; ++u) {
             const unsigned mw = mk[u * 32 + frow];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int pr = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                const int qr = tile * 32 + pr;
-                if (qr < 196) hrow[qr * C + u * 32 + frow] = ((mw >> pr) & 1u) ? acc[u][e] : 0.f;
+                tb[pr * 32 + frow] = ((mw >> pr) & 1u) ? acc[u][e] : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int qr = tile * 32 + p * 8 + er;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+                if (qr < 196) *reinterpret_cast<f32x4*>(hrow + qr * C + u * 32 + ec) = v;
             }
         }
     };
@@ -957,6 +967,7 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fh = lane >> 5;
+    float* tbuf = sg0 + 2 * CEB_IMG + wave * (32 * C);          // this wave's [32][C] store-transpose slice
     BwdWeights<C, 3, CE_GWP> bw;
     bw.load(a.F6, lane);
     // pin the fragments: without this the compiler re-issues the (invariant) filter loads inside the item loop
@@ -1019,13 +1030,20 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
                 for (int e = 0; e < 16; ++e) do_store |= acc[u][e] == 12345.678f;
         }
         if (do_store) {
+            // transpose the wave's [32 positions][C] result through its LDS slice: a lane then owns 4 consecutive channels and
+            // one store instruction writes 1 KB contiguous (8 b128 stores per item instead of 32 dword ones -- under load every
+            // VMEM instruction costs the issuing wave 100-300 cycles)
 #pragma unroll
             for (int u = 0; u < C / 32; ++u)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int owr = (e & 3) + 8 * (e >> 2) + 4 * fh;
-                    hrow[(oh * 32 + owr) * C + u * 32 + frow] = acc[u][e];
-                }
+                for (int e = 0; e < 16; ++e) tbuf[((e & 3) + 8 * (e >> 2) + 4 * fh) * C + u * 32 + frow] = acc[u][e];
+            constexpr int PPI = 256 / C;                           // positions per store instruction (64 lanes x 4 floats)
+            float* orow = hrow + (long long)oh * 32 * C;
+#pragma unroll
+            for (int p = 0; p < 32 / PPI; ++p) {
+                const int off = (p * PPI) * C + lane * 4;
+                *reinterpret_cast<f32x4*>(orow + off) = *reinterpret_cast<const f32x4*>(tbuf + off);
+            }
         }
         if (tr) t3 = (long long)__builtin_readcyclecounter();
         if (nxt < n_items && a.dbg != 7) park(sg0 + (buf ^ 1) * CEB_IMG, pf);
@@ -1082,7 +1100,12 @@ void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
     if (a.bwd_persist > 0) {
         const int n_items = a.n_rows * 8;
         const int grid = n_items < a.bwd_persist ? n_items : a.bwd_persist;
-        const int lds = 2 * CEB_IMG * 4;
+        const int lds = (2 * CEB_IMG + 4 * 32 * a.C) * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_bwd_persist_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * CEB_IMG + 4 * 32 * 128) * 4);
+            attr_done = true;
+        }
         if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<64>), dim3(grid), dim3(256), lds, s, a, n_items);
         else hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<128>), dim3(grid), dim3(256), lds, s, a, n_items);
         return;
