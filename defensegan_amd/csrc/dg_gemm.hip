@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 
 template <int BM, int BN, int MODE>
 static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
-    const int lds = 2 * (BM + BN) * ROW_BYTES + 16 + (a.lds_pad > 0 ? a.lds_pad : 0);
+    const int lds = 2 * (BM + BN) * ROW_BYTES + (a.lds_pad > 0 ? a.lds_pad : 0);   // 64x64: exactly 32 KB, five fit in 160 KB
     static int attr_lds = 0;
     if (attr_lds < lds) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),

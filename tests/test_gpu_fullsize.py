@@ -53,3 +53,24 @@ def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
     decided = (gap[:, 1] - gap[:, 0]) > 1e-6
     assert (dev["idx"][decided] == t["idx"][decided]).all()
     np.testing.assert_allclose(dev["loss"], t["loss"], rtol=0.05, atol=2e-6)
+
+
+@pytest.mark.parametrize("arch,B", [("mnist", 4500), ("celeba", 3400)])
+def test_large_batches_cross_the_32_bit_offset_limits(arch, B):
+    """45 000 / 34 000 latent rows: activation buffers beyond 2^31 bytes (MNIST) and beyond 2^31 ELEMENTS (CelebA h5:
+    34 000 x 65 536).  Rows are independent of the batch they are in, so the last images of the big batch must equal the
+    same images projected alone, bit for bit; an overflowing offset would corrupt exactly those."""
+    R, L = 10, 2
+    a = archs.make_arch(arch)
+    gan, p = make_gan(arch, gain=2.0, bias_range=0.05, rec_rr=R, rec_iters=L)
+    rs = np.random.RandomState(3)
+    zt = (rs.standard_normal((B, 128)) * 0.09).astype(np.float32)
+    x = np.asarray(gan.generate(zt))
+    z0 = synth.make_z(B * R, 128, seed=8)
+    big = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    assert np.isfinite(big["loss"]).all()
+    for sl in (slice(0, 3), slice(B - 3, B)):
+        rows = slice(sl.start * R, sl.stop * R)
+        small = gan.reconstruct(x[sl], z_init_val=z0[rows], return_details=True)
+        assert np.array_equal(small["rec"], big["rec"][sl]) and np.array_equal(small["loss"], big["loss"][rows])
+        assert np.array_equal(small["idx"], big["idx"][sl]) and np.array_equal(small["z"], big["z"][rows])
