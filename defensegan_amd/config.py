@@ -14,18 +14,37 @@ from typing import Dict, Optional
 
 import yaml
 
-CFG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfgs", "gans")
+DEFAULTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cfgs", "projection_defaults.yml")
 
 REC_KEYS = ("REC_ITERS", "REC_LR", "REC_RR", "BATCH_SIZE", "LATENT_DIM", "NET_DIM", "USE_BN", "IMAGE_DIM")
 
 
 def builtin_cfg(name: str) -> str:
-    """Path of a shipped config: mnist | fmnist | celeba."""
-    name = {"f-mnist": "fmnist"}.get(name.lower(), name.lower())
-    return os.path.join(CFG_DIR, name + ".yml")
+    """Spec of a shipped config, ``<defaults file>#<dataset>``: mnist | fmnist (f-mnist) | celeba."""
+    name = {"fmnist": "f-mnist"}.get(name.lower(), name.lower())
+    return DEFAULTS + "#" + name
+
+
+def _from_defaults(path: str, dataset: str) -> Dict:
+    with open(path, "r") as f:
+        d = yaml.safe_load(f)
+    if dataset not in d["datasets"]:
+        raise RuntimeError("[!] No built-in configuration for {}.".format(dataset))
+    c, e = d["common"], d["datasets"][dataset]
+    return {"BATCH_SIZE": c["batch_size"], "TEST_BATCH_SIZE": c["test_batch_size"], "USE_BN": c["use_bn"],
+            "LATENT_DIM": c["latent_dim"], "NET_DIM": e.get("net_dim", c["net_dim"]), "NUM_GPUS": c["num_gpus"],
+            "DATASET_NAME": dataset, "ARCH_TYPE": e["arch"], "IMAGE_DIM": list(e["image_dim"]),
+            "REC_ITERS": e["steps"], "REC_LR": float(e["lr"]), "REC_RR": e["restarts"]}
 
 
 def load_config(cfg_path: str) -> Dict:
+    """A built-in spec (``builtin_cfg``), a reference-style flat ``<cfg>.yml`` (merged over ``default.yml`` of the same
+    directory, utils/config.py:50-71) or a directory holding ``cfg.yml``."""
+    if "#" in cfg_path and os.path.exists(cfg_path.split("#", 1)[0]):
+        path, dataset = cfg_path.split("#", 1)
+        cfg = _from_defaults(path, dataset)
+        cfg["cfg_path"] = cfg_path
+        return cfg
     if not os.path.exists(cfg_path):
         raise RuntimeError("[!] Configuration path {} does not exist.".format(cfg_path))
     if os.path.isdir(cfg_path):

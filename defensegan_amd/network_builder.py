@@ -237,37 +237,46 @@ def conv_output_shape(shape, layer: Conv2D):
 
 
 # ---------------------------------------------------------------------- the reference's model zoo (network_builder.py:333-521)
-def model_f(nb_filters=64, nb_classes=10, input_shape=(None, 28, 28, 1), rec_model=None):
-    return MLP([Conv2D(nb_filters, (8, 8), (2, 2), "SAME"), ReLU(), Conv2D(nb_filters * 2, (6, 6), (2, 2), "VALID"), ReLU(),
-                Conv2D(nb_filters * 2, (5, 5), (1, 1), "VALID"), ReLU(), Flatten(), Linear(nb_classes), Softmax()],
-               input_shape, rec_model=rec_model)
-
-
-def model_e(input_shape=(None, 28, 28, 1), nb_classes=10):
-    return MLP([Flatten(), Linear(200), ReLU(), Linear(200), ReLU(), Linear(nb_classes), Softmax()], input_shape)
-
-
-def model_d(input_shape=(None, 28, 28, 1), nb_classes=10):
-    return MLP([Flatten(), Linear(200), ReLU(), Dropout(0.5), Linear(200), ReLU(), Linear(nb_classes), Softmax()], input_shape)
-
-
-def model_b(nb_filters=64, nb_classes=10, input_shape=(None, 28, 28, 1), rec_model=None):
-    return MLP([Dropout(0.2), Conv2D(nb_filters, (8, 8), (2, 2), "SAME"), ReLU(), Conv2D(nb_filters * 2, (6, 6), (2, 2), "VALID"),
-                ReLU(), Conv2D(nb_filters * 2, (5, 5), (1, 1), "VALID"), ReLU(), Dropout(0.5), Flatten(), Linear(nb_classes),
-                Softmax()], input_shape, rec_model=rec_model)
-
-
-def _conv_zoo(convs, hidden, nb_classes, input_shape, rec_model, drop_after_flatten=None):
+# Architectures are data: (channels, kernel, stride, padding) per Conv2D+ReLU stage, hidden widths per Linear+ReLU(+Dropout)
+# stage; the builders keep the reference's names and signatures.
+def _conv_zoo(convs, hidden, nb_classes, input_shape, rec_model, drop_after_flatten=None, drop_input=None, drop_before_flatten=None,
+              hidden_dropout=True):
     layers: List[Layer] = []
+    if drop_input is not None:
+        layers.append(Dropout(drop_input))
     for (ch, k, s, pad) in convs:
         layers += [Conv2D(ch, (k, k), (s, s), pad), ReLU()]
+    if drop_before_flatten is not None:
+        layers.append(Dropout(drop_before_flatten))
     layers.append(Flatten())
     if drop_after_flatten is not None:
         layers.append(Dropout(drop_after_flatten))
     for h in hidden:
-        layers += [Linear(h), ReLU(), Dropout(0.5)]
+        layers += [Linear(h), ReLU()] + ([Dropout(0.5)] if hidden_dropout else [])
     layers += [Linear(nb_classes), Softmax()]
     return MLP(layers, input_shape, rec_model=rec_model)
+
+
+_BF_CONVS = lambda f: [(f, 8, 2, "SAME"), (2 * f, 6, 2, "VALID"), (2 * f, 5, 1, "VALID")]
+
+
+def model_f(nb_filters=64, nb_classes=10, input_shape=(None, 28, 28, 1), rec_model=None):
+    return _conv_zoo(_BF_CONVS(nb_filters), [], nb_classes, input_shape, rec_model)
+
+
+def model_b(nb_filters=64, nb_classes=10, input_shape=(None, 28, 28, 1), rec_model=None):
+    return _conv_zoo(_BF_CONVS(nb_filters), [], nb_classes, input_shape, rec_model, drop_input=0.2, drop_before_flatten=0.5)
+
+
+def model_e(input_shape=(None, 28, 28, 1), nb_classes=10):
+    return _conv_zoo([], [200, 200], nb_classes, input_shape, None, hidden_dropout=False)
+
+
+def model_d(input_shape=(None, 28, 28, 1), nb_classes=10):
+    m = _conv_zoo([], [200, 200], nb_classes, input_shape, None, hidden_dropout=False)
+    layers = list(m.layers)
+    layers.insert(3, Dropout(0.5))          # Flatten, Linear(200), ReLU, Dropout(0.5), Linear(200), ReLU, Linear, Softmax
+    return MLP(layers, input_shape)
 
 
 def model_a(nb_filters=64, nb_classes=10, input_shape=(None, 28, 28, 1), rec_model=None):
