@@ -304,11 +304,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 template <int BM, int BN, int MODE>
 static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
     const int lds = 2 * (BM + BN) * ROW_BYTES + (a.lds_pad > 0 ? a.lds_pad : 0);   // 64x64: exactly 32 KB, five fit in 160 KB
-    static int attr_lds = 0;
-    if (attr_lds < lds) {
+    static PerDeviceOnce attr;
+    if (attr.need(lds)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
     }
     unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
                               : (unsigned)n_pos * (unsigned)a.n_mtiles;

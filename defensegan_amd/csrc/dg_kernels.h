@@ -7,6 +7,21 @@
 
 namespace dg {
 
+// hipFuncSetAttribute applies to the CURRENT device: "set it once" guards in the launchers are kept per device, so that a
+// process driving several GPUs (one handle each) raises the dynamic-LDS limit on every one of them.
+struct PerDeviceOnce {
+    int level[64] = {};
+    bool need(int want = 1) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        d &= 63;
+        if (level[d] >= want) return false;
+        level[d] = want;
+        return true;
+    }
+};
+
+
 // ---- gathered implicit GEMM -------------------------------------------------------------------
 // Out[n, pos, n0 + c] = epi( sum_{t in taps(pos)} sum_{k < kch} A[n*a_rowstride + a_off(t) + k]
 //                                                          * W[w_off(t) + (n0 + c)*w_rowstride + k] )

@@ -153,11 +153,10 @@ __global__ __launch_bounds__(256) void mnist_tail_kernel(MnistTailArgs a) {
 template <int C>
 static void launch_tail_c(const MnistTailArgs& a, hipStream_t s) {
     constexpr int lds = (HP * HP * C + GR * GW + 4) * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr;
+    if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_kernel<C>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
     }
     hipLaunchKernelGGL((mnist_tail_kernel<C>), dim3(a.n_rows), dim3(256), lds, s, a);
 }

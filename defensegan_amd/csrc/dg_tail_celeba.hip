@@ -180,12 +180,12 @@ __global__ __launch_bounds__(256) void celeba_loss_finish_kernel(const float* __
 void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s) {
     const int lds = (CB_IN_ROWS * CB_IN_COLS * a.C + 4) * 4;
     if (a.C == 64) {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+        static PerDeviceOnce attr;
+        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((celeba_tail_fwd_kernel<64>), dim3(a.n_rows * 8), dim3(256), lds, s, a);
     } else {
-        static bool done = false;
-        if (!done) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); done = true; }
+        static PerDeviceOnce attr;
+        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((celeba_tail_fwd_kernel<128>), dim3(a.n_rows * 8), dim3(256), lds, s, a);
     }
 }

@@ -563,11 +563,8 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
     if (a.pipe && a.do_backward && a.C == 64 && a.n_rows >= 2 * a.pipe) {
         constexpr int C = 64;
         const int lds = (2 * 224 * MN_NKP + 2 * MN_GR * MN_GWP + 2 * 224 * (C / 32) + 8 + (C / 8) * 256 + 13 * 64 * (C / 32)) * 4 + 8 * 32 * C * 4;
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static PerDeviceOnce attr;
+        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL((mnist_tail_pipe_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
         return;
     }
@@ -1068,16 +1065,15 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
 }
 
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
-    static bool done = false;
+    static PerDeviceOnce attr;
     const int lds32 = (192 * CE_NKP + 8) * 4;
     const int main16 = 6 * 32 * a.C * 4 > CE16_UNITS * CE16_UNIT * 4 ? 6 * 32 * a.C * 4 : CE16_UNITS * CE16_UNIT * 4;
     const int lds16 = main16 + 32;
-    if (!done) {
+    if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
-        done = true;
     }
     if (a.fwd16) {
         if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
@@ -1101,11 +1097,8 @@ void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
         const int n_items = a.n_rows * 8;
         const int grid = n_items < a.bwd_persist ? n_items : a.bwd_persist;
         const int lds = (2 * CEB_IMG + 4 * 32 * a.C) * 4;
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_bwd_persist_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * CEB_IMG + 4 * 32 * 128) * 4);
-            attr_done = true;
-        }
+        static PerDeviceOnce attr;
+        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_bwd_persist_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * CEB_IMG + 4 * 32 * 128) * 4);
         if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<64>), dim3(grid), dim3(256), lds, s, a, n_items);
         else hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<128>), dim3(grid), dim3(256), lds, s, a, n_items);
         return;
