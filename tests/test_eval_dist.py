@@ -196,3 +196,14 @@ def test_idx_ubyte_reader_and_split(tmp_path):
     assert g.min() >= 0 and g.max() <= 1
     c = datasets.to_generator_range(x, "celeba")
     assert c.min() >= -1 and c.max() <= 1
+
+
+def test_command_line_surface():
+    """python -m defensegan_amd keeps the reference's reconstruction flags (whitebox.py:358-395)."""
+    from defensegan_amd import __main__ as cli
+    a = cli.build_parser().parse_args(["--cfg", "celeba", "--init_path", "w.npz", "--input", "x.npy", "--output", "r.npy",
+                                       "--rec_iters", "50", "--rec_rr", "4", "--same_init"])
+    cfg = cfgmod.load_config(cli.resolve_cfg(a.cfg))
+    assert cfg["DATASET_NAME"] == "celeba" and cfg["IMAGE_DIM"] == [64, 64, 3]
+    assert cfgmod.resolve_rec_params(cfg, a) == {"rec_rr": 4, "rec_lr": 10.0, "rec_iters": 50, "batch_size": 50}
+    assert a.same_init and not a.raw and a.seed == 11241990

@@ -143,3 +143,18 @@ def test_load_generator_from_tensorflow_checkpoint(tmp_path):
     g3 = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True)
     with pytest.raises(ValueError, match="Generator.3.Filters"):
         g3.load_generator(str(tmp_path / "bad"))
+
+
+def test_command_line_projects_a_file(tmp_path):
+    """python -m defensegan_amd: weight pack + image stack in, reconstructions out, ragged batches; equals the API call."""
+    from defensegan_amd import __main__ as cli
+    gan, p = _make("mnist", R=3, L=4)
+    np.savez(str(tmp_path / "generator.npz"), **p)
+    x = np.asarray(gan.generate(synth.make_z(11, 128, seed=3)))
+    np.save(str(tmp_path / "x.npy"), x)
+    rc = cli.main(["--cfg", "mnist", "--init_path", str(tmp_path / "generator.npz"), "--input", str(tmp_path / "x.npy"),
+                   "--output", str(tmp_path / "rec.npy"), "--rec_rr", "3", "--rec_iters", "4", "--batch_size", "4", "--seed", "5"])
+    assert rc == 0
+    rec = np.load(str(tmp_path / "rec.npy"))
+    want = np.asarray(gan.reconstruct(x, seed=5, first_row=0))       # batch-composition independent, z0 keyed by global row
+    assert rec.shape == x.shape and np.array_equal(rec, want)
