@@ -158,3 +158,30 @@ def test_command_line_projects_a_file(tmp_path):
     rec = np.load(str(tmp_path / "rec.npy"))
     want = np.asarray(gan.reconstruct(x, seed=5, first_row=0))       # batch-composition independent, z0 keyed by global row
     assert rec.shape == x.shape and np.array_equal(rec, want)
+
+
+@pytest.mark.parametrize("arch", ["mnist", "celeba"])
+def test_divergent_runs_return_and_never_select_a_nan(arch):
+    """A step size far beyond stability: latents overflow, losses become inf/NaN.  The call must still return, indices
+    must be valid, and a restart with a NaN loss must never be selected while a finite one exists (strict "<" keeps the
+    first minimum; all-NaN images select restart 0)."""
+    a = archs.make_arch(arch)
+    B, R = 6, 4
+    gan, p = _make(arch, gain=3.0, R=R, L=6)
+    rs = np.random.RandomState(1)
+    x = np.asarray(gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))
+    z0 = synth.make_z(B * R, 128, seed=2)
+    z0[1::R] *= 0.0                                              # one restart per image starts at z = 0 and ...
+    gan.rec_lr = 1e9
+    out = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    loss = out["loss"].reshape(B, R)
+    assert out["idx"].min() >= 0 and out["idx"].max() < R
+    for b in range(B):
+        finite = np.isfinite(loss[b])
+        if finite.any():
+            assert finite[out["idx"][b]] and loss[b, out["idx"][b]] == loss[b][finite].min()
+        else:
+            assert out["idx"][b] == 0
+    gan.rec_lr = 10.0
+    ok = gan.reconstruct(x, z_init_val=z0, return_details=True)    # the handle is still usable afterwards
+    assert np.isfinite(ok["loss"]).all()
