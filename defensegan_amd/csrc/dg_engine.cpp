@@ -465,7 +465,6 @@ void run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, 
 struct RowGroup {
     int row0 = 0, n_rows = 0;
     hipStream_t s = nullptr;
-    int index = 0;               // which per-stream scratch (item queues) the group uses
 };
 
 dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
@@ -869,7 +868,6 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
             grp[gi].row0 = b_done * R;
             grp[gi].n_rows = nb * R;
             grp[gi].s = gi == 0 ? s : h->side_stream[gi - 1];
-            grp[gi].index = gi;
             b_done += nb;
         }
         HIP_TRY(hipEventRecord(h->ev_fork, s));
