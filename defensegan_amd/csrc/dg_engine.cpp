@@ -264,16 +264,15 @@ int upload_plan(GemmOp& op) {
     return DG_OK;
 }
 
+// Tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very different K (1..9 or
+// 4..25 taps) and B*R ~ 1280-2560 gives only 20-40 M tiles, so the choice trades the steady-state rate of bigger tiles
+// (128x128: 136 TF, 64x128 / 128x64: 131, 64x64: 127) against dispatch balance.  Measured per layer on MI355X (DESIGN.md
+// section 4.1): the smallest tile wins or ties on every layer of both architectures at these row counts (e.g. MNIST B3
+// 401 -> 367 us, B2 360 -> 336, CelebA F2 230 -> 211; MNIST F2 ties), also under the balanced persistent tile lists.
+// `tile.<op>` overrides it per layer.
 int default_tile(const std::string& name, int ncols) {
-    // tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very different K
-    // (1..9 or 4..25 taps) and B*R ~ 2560 gives only 20-40 M tiles, so the choice trades steady-state rate
-    // (128x128: 136 TF, 64x128: 126 TF) against dispatch balance; values measured per layer on MI355X at N = 2560
-    // (gpurun_out/t36_probe.log: F1 44.5 -> 37.1 us, F2 331.7 -> 322.9, F3 377.1 -> 364.1, B1 41.3 -> 33.4).
-    if (name == "F1" || name == "B1") return 3;          // K = latent / split-K: short tiles, many of them
-    if (ncols % 128 != 0) return 3;                       // 64 output columns (Generator.3 fwd, Generator.5)
-    // With the interleaved-DMA K loop the smallest tile wins or ties everywhere at these row counts: balance and
-    // occupancy (5 workgroups/CU) outweigh its higher staging traffic (B3 401 -> 367 us, B2 360 -> 336 us, CelebA
-    // F2 at N = 1280: 230 -> 211 us; MNIST F2 ties at 316-317 us for 128x128 / 64x128 / 64x64).
+    (void)name;
+    (void)ncols;
     return 3;
 }
 
