@@ -18,7 +18,7 @@
 
 #include "../../include/defensegan_hip.h"
 
-extern "C" void dg_set_error_message(const char* msg);      // dg_engine.cpp (dg_last_error storage)
+extern "C" __attribute__((visibility("hidden"))) void dg_set_error_message(const char* msg);   // dg_engine.cpp (dg_last_error storage), library-internal
 
 namespace {
 

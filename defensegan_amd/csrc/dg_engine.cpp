@@ -600,7 +600,7 @@ int dg_version(void) { return DG_ABI_VERSION; }
 const char* dg_last_error(void) { return g_err.c_str(); }
 
 // internal: lets the other translation units of the library (dg_clf.hip) report through dg_last_error()
-void dg_set_error_message(const char* msg) { g_err = msg ? msg : ""; }
+__attribute__((visibility("hidden"))) void dg_set_error_message(const char* msg) { g_err = msg ? msg : ""; }
 
 int dg_device_count(void) {
     int n = 0;
