@@ -189,3 +189,16 @@ def test_attack_then_defend_pipeline_runs_on_device():
     labels = bbox(x).argmax(axis=1)
     c, n, roc = gan_defense.model_eval_gan(gan.reconstruct, bbox, x_adv, labels, batch_size=5, rec_rr=2, seed=1)
     assert n == 12 and 0 <= c <= 12 and (roc[2] > 0).all()       # adversarial inputs are off the generator's range
+
+
+@pytest.mark.gpu
+def test_classifier_errors_are_reported_through_dg_last_error():
+    from defensegan_amd import _native
+    m = nb.model_e()
+    with pytest.raises(_native.NativeError):
+        m(np.zeros((2, 28, 28, 1), np.float32))                     # weights not set
+    with pytest.raises(_native.NativeError, match=r"Linear W must be \[784,200\]"):
+        m.set_weights([(np.zeros((10, 200), np.float32), np.zeros(200, np.float32))] * 3)
+    bad = nb.MLP([nb.Linear(10)], (None, 28, 28, 1))               # Linear without Flatten
+    with pytest.raises(_native.NativeError, match="Flatten"):
+        bad._ensure()
