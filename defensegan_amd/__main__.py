@@ -38,6 +38,15 @@ def main(argv=None) -> int:
     rp = config.resolve_rec_params(cfg, args)
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        use_cuda = torch.cuda.is_available()
+        if use_cuda:
+            torch.cuda.set_device(local)         # before any CUDA / RCCL use: one process per GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl" if use_cuda else "gloo",
+                                **({"device_id": torch.device("cuda", local)} if use_cuda else {}))
     gan = gan_from_config(cfg_path, rec_rr=rp["rec_rr"], rec_iters=rp["rec_iters"], rec_lr=rp["rec_lr"], device=local)
     gan.load_generator(args.init_path)
     x = np.load(args.input).astype(np.float32)
@@ -55,13 +64,7 @@ def main(argv=None) -> int:
         kw = {"z_init_val": z_same[: (b1 - b0) * rp["rec_rr"]]} if z_same is not None else {}
         out[b0 - s:b1 - s] = np.asarray(gan.reconstruct(x[b0:b1], seed=args.seed, first_row=b0 * rp["rec_rr"], **kw))
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-        parts = [None] * world
-        dist.all_gather_object(parts, out)
-        out = np.concatenate(parts)
+        out = gan_defense.gather_shards(out, n)          # one tensor all_gather (RCCL over xGMI), no pickling
         dist.destroy_process_group()
     if rank == 0:
         np.save(args.output, out)

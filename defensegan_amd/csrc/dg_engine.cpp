@@ -122,7 +122,6 @@ struct dg_handle {
     int nsplit = 8;
     int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
     int lds_pad = 0;
-    int tail_mfma = 1;
     int persistent = 1;            // balanced persistent tile lists (dg_gemm.hip): 0 = never, 1 = where measured to pay, 2 = every layer
     int persist_wgs = 0;           // resident workgroups per CU in persistent mode, 0 = by the tile's LDS footprint
     int tail_dbg = 0;
@@ -247,8 +246,12 @@ const GemmSchedule* get_schedule(GemmOp& op, int tile, int n_mtiles, int grid) {
     sc.tile = tile; sc.n_mtiles = n_mtiles; sc.grid = grid;
     if (hipMalloc(&sc.d_off, off.size() * sizeof(unsigned)) != hipSuccess) return nullptr;
     if (hipMalloc(&sc.d_list, flat.size() * sizeof(unsigned)) != hipSuccess) { (void)hipFree(sc.d_off); return nullptr; }
-    (void)hipMemcpy(sc.d_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice);
-    (void)hipMemcpy(sc.d_list, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice);
+    if (hipMemcpy(sc.d_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(sc.d_list, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(sc.d_off);
+        (void)hipFree(sc.d_list);
+        return nullptr;              // the caller falls back to one workgroup per tile
+    }
     op.sched.push_back(sc);
     return &op.sched.back();
 }
@@ -517,10 +520,10 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         t.pipe = h->tail_pipe;
         t.trace = h->d_tail_trace;
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
-        const bool piped = h->tail_mfma && t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
+        const bool piped = t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
         ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? "T5fb@mnist_tail_pipe_kernel" : "T5fb@mnist_tail_mfma_kernel",
                      (tail_backward ? 4.0 : 2.0) * macs * n_rows);
-        if (h->tail_mfma) dg::launch_mnist_tail_mfma(t, s); else dg::launch_mnist_tail(t, s);
+        dg::launch_mnist_tail_mfma(t, s);
     } else {
         dg::CelebaTailArgs t;
         t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
@@ -543,12 +546,12 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
             ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
-            if (h->tail_mfma) dg::launch_celeba_tail_fwd_mfma(t, s); else dg::launch_celeba_tail_fwd(t, s);
+            dg::launch_celeba_tail_fwd_mfma(t, s);
         }
         dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
         if (tail_backward) {
             ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
-            if (h->tail_mfma) dg::launch_celeba_tail_bwd_mfma(t, s); else dg::launch_celeba_tail_bwd(t, s);
+            dg::launch_celeba_tail_bwd_mfma(t, s);
         }
     }
 }
@@ -583,6 +586,15 @@ int rebuild_plans(dg_handle* h) {
         h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
         h->Bd[d].W = h->Ft[d];
     }
+    return DG_OK;
+}
+
+// One call processes at most 2^24 latent rows (32-bit tile arithmetic in the launchers).
+int check_rows(int B, int R, int* n_rows) {
+    if (B < 1 || R < 1) return fail(DG_E_INVALID, "need B >= 1 and R >= 1 (got %d, %d)", B, R);
+    const int64_t rows64 = (int64_t)B * R;
+    if (rows64 > (1 << 24)) return fail(DG_E_INVALID, "B*R = %lld is too large for one call", (long long)rows64);
+    *n_rows = (int)rows64;
     return DG_OK;
 }
 
@@ -719,20 +731,42 @@ int dg_destroy(dg_handle* h) {
 
 int dg_set_weights(dg_handle* h, const char* name, const float* data, const int64_t* shape, int ndim, int is_device) {
     if (!h || !name || !data || !shape) return fail(DG_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
+    const std::string nm(name);
+    // Resolve the name to the shape it must have BEFORE anything is sized or copied from the caller's pointer.
+    std::vector<int64_t> want;
+    bool any_shape = false;          // BN scale / offset: the reference stores them with the keep_dims shape of the moments
+    if (nm == "Generator.Input.W") want = {h->latent, h->lin_out};
+    else if (nm == "Generator.Input.b") want = {h->lin_out};
+    for (const DeconvSpec& s : h->dec) {
+        if (nm == std::string(s.name) + ".Filters") want = {5, 5, s.cout, s.cin};
+        else if (nm == std::string(s.name) + ".Biases") want = {s.cout};
+    }
+    for (const ActInfo& a : h->ai)
+        if (a.has_bn && (nm == a.bn_name + ".scale" || nm == a.bn_name + ".offset")) { want = {a.bn_C}; any_shape = true; }
+    if (want.empty()) return fail(DG_E_INVALID, "unknown weight name '%s'", name);
+    int64_t n_want = 1;
+    for (int64_t w : want) n_want *= w;
+    if (ndim < 1 || ndim > 8) return fail(DG_E_INVALID, "%s: ndim %d out of range", name, ndim);
     int64_t n = 1;
-    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] <= 0 || shape[i] > n_want) return fail(DG_E_INVALID, "%s: dimension %d is %lld", name, i, (long long)shape[i]);
+        n *= shape[i];
+        if (n > n_want) break;
+    }
+    bool shape_ok = n == n_want;
+    if (shape_ok && !any_shape) {
+        shape_ok = ndim == (int)want.size();
+        for (int i = 0; shape_ok && i < ndim; ++i) shape_ok = shape[i] == want[i];
+    }
+    if (!shape_ok) {
+        std::string w;
+        for (size_t i = 0; i < want.size(); ++i) w += (i ? "," : "") + std::to_string(want[i]);
+        return fail(DG_E_INVALID, any_shape ? "%s: expected %s values" : "%s: expected shape [%s]", name, w.c_str());
+    }
+    HIP_TRY(hipSetDevice(h->device));
     std::vector<float> host((size_t)n);
     HIP_TRY(hipMemcpy(host.data(), data, (size_t)n * sizeof(float), is_device ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
-    const std::string nm(name);
-    auto shape_is = [&](std::initializer_list<int64_t> want) {
-        if ((int)want.size() != ndim) return false;
-        int i = 0;
-        for (int64_t w : want) if (shape[i++] != w) return false;
-        return true;
-    };
     if (nm == "Generator.Input.W") {
-        if (!shape_is({h->latent, h->lin_out})) return fail(DG_E_INVALID, "%s: expected shape [%d,%d]", name, h->latent, h->lin_out);
         std::vector<float> t((size_t)n);
         for (int d = 0; d < h->latent; ++d)
             for (int f = 0; f < h->lin_out; ++f) t[(size_t)f * h->latent + d] = host[(size_t)d * h->lin_out + f];
@@ -742,7 +776,6 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
         return DG_OK;
     }
     if (nm == "Generator.Input.b") {
-        if (!shape_is({h->lin_out})) return fail(DG_E_INVALID, "%s: expected shape [%d]", name, h->lin_out);
         HIP_TRY(hipMemcpy(h->lin_b, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         h->have[nm] = true;
         return DG_OK;
@@ -750,7 +783,6 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
     for (size_t d = 0; d < h->dec.size(); ++d) {
         const DeconvSpec& s = h->dec[d];
         if (nm == std::string(s.name) + ".Filters") {
-            if (!shape_is({5, 5, s.cout, s.cin})) return fail(DG_E_INVALID, "%s: expected shape [5,5,%d,%d]", name, s.cout, s.cin);
             std::vector<float> t((size_t)n);
             for (int k = 0; k < 25; ++k)
                 for (int co = 0; co < s.cout; ++co)
@@ -793,7 +825,6 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
             return DG_OK;
         }
         if (nm == std::string(s.name) + ".Biases") {
-            if (!shape_is({s.cout})) return fail(DG_E_INVALID, "%s: expected shape [%d]", name, s.cout);
             HIP_TRY(hipMemcpy(h->bias[d], host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
             h->have[nm] = true;
             return DG_OK;
@@ -803,9 +834,6 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
         if (!a.has_bn) continue;
         for (int which = 0; which < 2; ++which) {
             if (nm != a.bn_name + (which ? ".offset" : ".scale")) continue;
-            // the reference keeps these with the keep_dims shape of the moments ([1,C] / [1,1,1,C]); accept any
-            // shape with bn_C elements
-            if (n != a.bn_C) return fail(DG_E_INVALID, "%s: expected %d values", name, a.bn_C);
             HIP_TRY(hipMemcpy(which ? a.offset : a.scale, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
             h->have[nm] = true;
             return DG_OK;
@@ -841,12 +869,12 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     int rc = check_ready(h);
     if (rc) return rc;
     if (!x || !out_rec) return fail(DG_E_INVALID, "x and out_rec must be non-null");
-    if (B < 1 || R < 1 || L < 0) return fail(DG_E_INVALID, "need B >= 1, R >= 1, L >= 0 (got %d, %d, %d)", B, R, L);
+    if (L < 0) return fail(DG_E_INVALID, "need L >= 0 (got %d)", L);
+    int n_rows = 0;
+    rc = check_rows(B, R, &n_rows);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int64_t rows64 = (int64_t)B * R;
-    if (rows64 > (1 << 24)) return fail(DG_E_INVALID, "B*R = %lld is too large for one call", (long long)rows64);
-    const int n_rows = (int)rows64;
     rc = ensure_workspace(h, n_rows);
     if (rc) return rc;
     const size_t zbytes = (size_t)n_rows * h->latent * sizeof(float);
@@ -900,7 +928,10 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
 int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!z || !out_y || N < 1) return fail(DG_E_INVALID, "bad argument");
+    if (!z || !out_y) return fail(DG_E_INVALID, "bad argument");
+    int n_checked = 0;
+    rc = check_rows(N, 1, &n_checked);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     rc = ensure_workspace(h, N);
@@ -918,10 +949,12 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
                  float* out_dz, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
-    if (!x || !z || B < 1 || R < 1) return fail(DG_E_INVALID, "bad argument");
+    if (!x || !z) return fail(DG_E_INVALID, "bad argument");
+    int n_rows = 0;
+    rc = check_rows(B, R, &n_rows);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    const int n_rows = B * R;
     rc = ensure_workspace(h, n_rows);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1051,10 +1084,6 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "persist_wgs") {
         h->persist_wgs = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_mfma") {
-        h->tail_mfma = atoi(value) ? 1 : 0;
         return DG_OK;
     }
     if (k == "lds_pad") {

@@ -85,8 +85,7 @@ struct MnistTailArgs {
     long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr
     int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
 };
-void launch_mnist_tail(const MnistTailArgs& a, hipStream_t s);        // VALU formulation (dg_tail.hip)
-void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // MFMA formulation (dg_tail_mfma.hip)
+void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail_mfma.hip
 
 // ---- CelebA tail: Generator.6 (64 -> 3, 64x64) + tanh + loss + backward to da5 ----------------
 struct CelebaTailArgs {
@@ -108,9 +107,7 @@ struct CelebaTailArgs {
     long long* trace;    // optional per-workgroup phase cycle totals [grid][8] (persistent backward tail), or nullptr
     int bwd_persist;     // backward MFMA tail: > 0 = persistent pipelined kernel with this many workgroups
 };
-void launch_celeba_tail_fwd(const CelebaTailArgs& a, hipStream_t s);       // VALU formulation
-void launch_celeba_tail_bwd(const CelebaTailArgs& a, hipStream_t s);
-void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // MFMA formulation
+void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // dg_tail_mfma.hip
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s);
 void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s);
 

@@ -118,4 +118,19 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
                        (unsigned long long)seed, (long long)first_row, std);
 }
 
+// ---- CelebA loss: sum of the per-band partial squared errors of a latent row, / P (gan.py:410-414) ----
+__global__ __launch_bounds__(256) void celeba_loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss,
+                                                                 int n_rows, int nparts, float inv_p) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_rows) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += part[(long long)n * nparts + k];
+    loss[n] = s * inv_p;
+}
+
+void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s) {
+    hipLaunchKernelGGL(celeba_loss_finish_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, loss_part, loss, n_rows,
+                       nparts, 1.0f / 12288.0f);
+}
+
 }  // namespace dg

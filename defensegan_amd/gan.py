@@ -134,7 +134,14 @@ class DefenseGANBase(object):
         for k, v in weights.items():
             if k not in want:
                 continue
-            if tuple(v.shape) != tuple(want[k]):
+            v = np.asarray(v)
+            if k.endswith(".scale") or k.endswith(".offset"):
+                # tflib Batchnorm stores these with the keep_dims shape of the moments: [1,4096] for BN1,
+                # [1,1,1,C] for BN2/BN3 (tflib/ops/batchnorm.py:83-89); any shape with C values is accepted
+                if v.size != int(np.prod(want[k])):
+                    raise ValueError("%s: shape %r, expected %d values" % (k, tuple(v.shape), int(np.prod(want[k]))))
+                v = v.reshape(want[k])
+            elif tuple(v.shape) != tuple(want[k]):
                 raise ValueError("%s: shape %r, expected %r" % (k, tuple(v.shape), want[k]))
             self._weights[k] = np.ascontiguousarray(v, np.float32)
             if self._handle is not None:
@@ -173,8 +180,9 @@ class DefenseGANBase(object):
     def save_ds(self, splits, root: str = "data/cache", test_again: bool = False):
         """Counterpart of ``save_ds`` (gan.py:604-646): ``<root>/<dataset>_pkl/<split>/feats.pkl`` holding two consecutive
         pickles, the transformed images ``[n,H,W,C]`` (``input_transform`` of the raw [0,255] data) and the targets.
-        ``splits``: {'train'|'dev'|'test': (raw images, targets)}.  Protocol 2, so the Python-2 reference can read it."""
-        import pickle
+        ``splits``: {'train'|'dev'|'test': (raw images, targets)}.  Written by ``py2pickle`` (protocol 2, Python-2-era
+        NumPy module paths) so the Python-2 reference can read it."""
+        from . import py2pickle
         out = {}
         for split, (images, targets) in splits.items():
             out_dir = os.path.join(root, "{}_pkl".format(self.dataset_name or self.arch_name), split)
@@ -185,8 +193,8 @@ class DefenseGANBase(object):
                 continue
             x = self.input_transform(np.asarray(images, np.float32)).reshape([-1] + list(self.image_dim)).astype(np.float32)
             with open(path, "wb") as f:
-                pickle.dump(x, f, protocol=2)
-                pickle.dump(np.asarray(targets), f, protocol=2)
+                py2pickle.dump(x, f)
+                py2pickle.dump(np.asarray(targets), f)
         return out
 
     # ------------------------------------------------------------------ the hot path
@@ -269,11 +277,15 @@ class DefenseGANBase(object):
         Reconstructions are cached exactly where the reference caches them, so its readers find them:
         ``<checkpoint_dir>/recs_rr{R}_lr{lr:.5f}_iters{L}[_num{max_num}]/<split>/pickles/rec_{i:07d}_l{label}.pkl``
         (one array per image, gan.py:504-557; directory name parsed back by whitebox.py:252-257).  Pickles are
-        written with protocol 2 so that the Python-2 reference can load them.  A batch whose pickles all exist is
+        written by ``py2pickle`` (protocol 2 + ``numpy.core`` module paths) so that the Python-2 reference can load them.  A batch whose pickles all exist is
         loaded instead of recomputed unless ``test_again``.  Returns {split: [recs, targets, originals]} (gan.py:585).
         """
         import pickle
+        from . import py2pickle
         bs = int(batch_size or self.test_batch_size)
+        if seed is None:
+            seed = self._default_seed        # one seed per call: z0 rows are keyed by (seed, global row), not by how many
+                                             # batches happened to be computed rather than loaded from the cache
         name = _config.rec_dir_name(int(self.rec_rr), float(self.rec_lr), int(self.rec_iters))
         if max_num > 0:
             name += "_num{:d}".format(max_num)
@@ -310,7 +322,7 @@ class DefenseGANBase(object):
                     batch = np.asarray(batch.cpu().numpy() if hasattr(batch, "cpu") else batch, np.float32)
                     for q, r in zip(paths, batch):
                         with open(q, "wb") as f:
-                            pickle.dump(r, f, protocol=2)
+                            py2pickle.dump(r, f)
                 recs.append(batch)
             all_recs = np.concatenate(recs).reshape([-1] + list(self.image_dim)) if recs else np.zeros([0] + list(self.image_dim), np.float32)
             rets[split] = [all_recs, np.asarray(targets[:n]), np.asarray(images[:n]).reshape([-1] + list(self.image_dim))]

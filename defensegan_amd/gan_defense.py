@@ -88,6 +88,24 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
     return correct, n, [labels.astype(np.int64), preds_all, diffs_all]
 
 
+def gather_shards(local_rows: np.ndarray, n_total: int, group=None, device=None) -> np.ndarray:
+    """Assembles the per-rank contiguous shards (``shard_range``) of an [n_total, ...] float32 array on every rank with
+    ONE tensor all_gather (padded to the largest shard) -- RCCL over xGMI when the group's backend is nccl."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+    assert len(local_rows) == sizes[rank], (len(local_rows), sizes[rank])
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+    tail = tuple(local_rows.shape[1:])
+    buf = torch.zeros((max(sizes),) + tail, dtype=torch.float32, device=device)
+    buf[:sizes[rank]] = torch.from_numpy(np.ascontiguousarray(local_rows, np.float32))
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return np.concatenate([t[:k].cpu().numpy() for t, k in zip(out, sizes)])
+
+
 def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, batch_size: int, rec_rr: int = 1,
                            group=None, device=None, **kw):
     """Batch-sharded evaluation over a torch.distributed group: every rank evaluates its contiguous shard,

@@ -308,9 +308,22 @@ MODELS = {"A": model_a, "B": model_b, "C": model_c, "D": model_d, "E": model_e, 
 
 
 # ---------------------------------------------------------------------- the step BEFORE the path: FGSM
-def _mlp_input_gradient(self, x, labels=None):
-    """d(sum_b CE(softmax(logits_b), y_b))/dx on the device; y = ``labels`` (class indices) or the model's own prediction."""
+_REC_GRADIENT_NOTE = (
+    "the model has the Defense-GAN reconstruction layer attached (add_rec_model): the reference differentiates "
+    "THROUGH ReconstructionLayer (whitebox.py:185-214, network_builder.py:266-271), whose gradient w.r.t. its input is "
+    "identically zero (the projected latents live in variables updated by ApplyMomentum; the selected restart comes "
+    "from an argmin) -- the input gradient is 0 and FGSM returns clip(x).  Build the attack before add_rec_model (or "
+    "pass no_rec=True) to differentiate the bare classifier.")
+
+
+def _mlp_input_gradient(self, x, labels=None, no_rec=False):
+    """d(sum_b CE(softmax(logits_b), y_b))/dx on the device; y = ``labels`` (class indices) or the model's own prediction.
+    With the reconstruction layer attached the result is the reference's: zeros (see _REC_GRADIENT_NOTE)."""
     import torch
+    if self.rec_layer is not None and not no_rec:
+        import warnings
+        warnings.warn(_REC_GRADIENT_NOTE, stacklevel=2)
+        return np.zeros_like(x) if isinstance(x, np.ndarray) else torch.zeros_like(x)
     self._ensure()
     if not self._weights_set:
         raise _native.NativeError("classifier weights not set")
@@ -334,7 +347,11 @@ MLP.input_gradient = _mlp_input_gradient
 class FastGradientMethod(object):
     """The cleverhans attack object the reference instantiates (whitebox.py:198-200, blackbox.py:530-534), ord = inf only:
     ``adv = clip(x + eps * sign(grad_x CE(model(x), y)), clip_min, clip_max)``; without ``y`` the model's own prediction is
-    the label (cleverhans' default).  ``sess`` / ``back`` are accepted for signature compatibility and ignored."""
+    the label (cleverhans' default).  ``sess`` / ``back`` are accepted for signature compatibility and ignored.
+
+    White-box use on a DEFENDED model (whitebox.py:185-200 attaches the reconstruction layer first, then builds the attack
+    on that model): the gradient through the projection is identically zero in the reference, so ``generate`` returns
+    ``clip(x, clip_min, clip_max)`` -- reproduced here, with a warning."""
 
     def __init__(self, model: MLP, back="tf", sess=None):
         self.model = model
@@ -348,6 +365,13 @@ class FastGradientMethod(object):
         was_numpy = isinstance(x, np.ndarray)
         dev = torch.device("cuda", m._device)
         t = (torch.from_numpy(np.ascontiguousarray(x, np.float32)) if was_numpy else x).to(device=dev, dtype=torch.float32).contiguous()
+        lo = float("-inf") if clip_min is None else float(clip_min)
+        hi = float("inf") if clip_max is None else float(clip_max)
+        if m.rec_layer is not None:
+            import warnings
+            warnings.warn(_REC_GRADIENT_NOTE, stacklevel=2)
+            out = torch.clamp(t, lo, hi)                 # x + eps * sign(0)
+            return out.cpu().numpy() if was_numpy else out
         lab = None
         if y is not None:
             yy = y if isinstance(y, np.ndarray) else y.detach().cpu().numpy()
@@ -355,8 +379,6 @@ class FastGradientMethod(object):
                 yy = yy.argmax(axis=-1)                            # one-hot labels as cleverhans takes them
             lab = torch.from_numpy(np.ascontiguousarray(yy)).to(device=dev, dtype=torch.int32)
         out = torch.empty_like(t)
-        lo = float("-inf") if clip_min is None else float(clip_min)
-        hi = float("inf") if clip_max is None else float(clip_max)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
             _native.check(_native.load().dg_fgsm(m._handle, t.data_ptr(), lab.data_ptr() if lab is not None else None,

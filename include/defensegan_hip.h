@@ -133,13 +133,12 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "persist_wgs"      resident workgroups per CU in persistent mode (0 = by the tile's LDS footprint)
  *   "nsplit"           split-K factor of the Linear backward (default 8)
  *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
- *   "tail_mfma"        0 = VALU formulation of the tails (cross-check), 1 = MFMA (default)
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd16"       CelebA forward tail: 1 = 16x16x4 kh-aligned (default), 0 = 32x32x2
  *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel (0 = per-band kernel, "tail_bwd_bands")
  *   "tail_trace", "tail_dbg", "clk_probe", "xcd_map", "lds_pad"   measurement experiments (tools/)
- * Every launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py); "nsplit", "tail_fwd16" and
- * "tail_mfma" change a summation order (agreement to rounding).
+ * Every launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py); "nsplit" and "tail_fwd16" change
+ * a summation order (agreement to rounding).
  */
 int dg_set_option(dg_handle* h, const char* key, const char* value);
 

@@ -202,3 +202,34 @@ def test_classifier_errors_are_reported_through_dg_last_error():
     bad = nb.MLP([nb.Linear(10)], (None, 28, 28, 1))               # Linear without Flatten
     with pytest.raises(_native.NativeError, match="Flatten"):
         bad._ensure()
+
+
+@pytest.mark.gpu
+def test_whitebox_fgsm_through_the_defense_reproduces_the_reference():
+    """whitebox.py:185-223 in miniature (BASELINE configs[4]): the reconstruction layer is attached FIRST, then FGSM is built
+    on that model.  The reference's gradient through ReconstructionLayer is identically zero, so
+    ``adv_x == clip(x)``, ``diff_op = mean((adv_x - x)^2) == 0`` for in-range inputs, and the evaluated predictions are those
+    of classifier(reconstruct(x)).  The bare-classifier attack stays available through no_rec / building it earlier."""
+    from defensegan_amd import gan_defense
+    from tests.helpers import clean_targets, make_gan
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=2, rec_iters=6)
+    x, _ = clean_targets(p, "mnist", 10, seed=16)
+    x[0, :2, :2, 0] = [[1.4, -0.3], [0.5, 2.0]]                    # out-of-range pixels: only the clip acts on them
+    model = nb.model_a(nb_filters=8)
+    model.init_like_reference(seed=5)
+    bare_attack = nb.FastGradientMethod(model).generate(x, eps=0.3, clip_min=0.0, clip_max=1.0)
+    model.add_rec_model(gan, None, 5)
+    with pytest.warns(UserWarning, match="whitebox.py:185-214"):
+        adv = nb.FastGradientMethod(model).generate(x, eps=0.3, ord=np.inf, clip_min=0.0, clip_max=1.0)
+    assert np.array_equal(adv, np.clip(x, 0.0, 1.0))
+    assert np.abs(bare_attack - np.clip(x, 0, 1)).max() > 0.25       # the undefended model does yield a real attack
+    with pytest.warns(UserWarning):
+        assert not np.asarray(model.input_gradient(x)).any()
+    assert np.asarray(model.input_gradient(x, no_rec=True)).any()
+    # evaluation as whitebox.py:214-223: predictions of the defended model on adv_x, diffs = mean((adv_x - x)^2)
+    labels = model.fprop(adv, no_rec=True)["logits"].argmax(axis=1)
+    clf = lambda im: model.fprop(im, no_rec=True)["probs"]           # the harness applies the projection itself
+    c, n, roc = gan_defense.model_eval_gan(gan.reconstruct, clf, adv, labels, batch_size=5, rec_rr=2, seed=3)
+    assert n == 10 and 0 <= c <= 10
+    diff_op = ((adv - x) ** 2).reshape(10, -1).mean(axis=1)
+    assert (diff_op[1:] == 0).all() and diff_op[0] > 0

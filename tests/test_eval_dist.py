@@ -63,6 +63,10 @@ def _worker(rank, world, port, q):
         y = rs.randint(0, 2, 37)
         calls = []
         acc, roc = gd.model_eval_gan_sharded(fake_reconstruct(calls), classifier, x, y, batch_size=8, rec_rr=2)
+        # the CLI's gather of the reconstructions themselves: contiguous shards -> the whole array on every rank
+        s0, e0 = gd.shard_range(len(x), rank, world)
+        whole = gd.gather_shards(x[s0:e0] * 0.5, len(x))
+        assert whole.shape == x.shape and np.array_equal(whole, x * 0.5)
         q.put((rank, acc, roc[0].tolist(), roc[1].tolist(), roc[2].tolist(), calls))
     finally:
         dist.destroy_process_group()
@@ -129,6 +133,27 @@ def test_gan_object_surface_without_gpu():
             gan.reconstruct(np.zeros((1, 28, 28, 1), np.float32))
 
 
+def _assert_python2_era_numpy_can_unpickle(raw, n_objects):
+    """The reference reads these files with cPickle under Python 2 and NumPy <= 1.16 (gan.py:489, 527): protocol <= 2 and
+    every global must exist there -- ``numpy.core.multiarray._reconstruct`` / ``numpy.ndarray`` / ``numpy.dtype`` /
+    ``_codecs.encode``; NumPy >= 2's own pickles name ``numpy._core.multiarray``, which that NumPy cannot import."""
+    import io
+    import pickle
+    import pickletools
+    assert b"numpy._core" not in raw and b"numpy.core.multiarray" in raw
+    allowed = {("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy", "ndarray"),
+               ("numpy", "dtype"), ("_codecs", "encode")}
+    f = io.BytesIO(raw)
+    for _ in range(n_objects):
+        ops = list(pickletools.genops(f))
+        assert ops[0][0].name == "PROTO" and ops[0][1] == 2
+        for op, arg, _pos in ops:
+            assert op.proto <= 2, op.name
+            if op.name == "GLOBAL":
+                assert tuple(arg.split(" ")) in allowed, arg
+    assert f.read() == b""
+
+
 def test_reconstruct_dataset_cache_layout(tmp_path):
     """reconstruct_dataset writes the reference's cache layout (gan.py:467-478, 504-557) and reloads it."""
     import pickle
@@ -146,6 +171,7 @@ def test_reconstruct_dataset_cache_layout(tmp_path):
     d = tmp_path / "recs_rr2_lr10.00000_iters5" / "test" / "pickles"
     assert sorted(p.name for p in d.iterdir())[0] == "rec_0000000_l0.pkl" and len(list(d.iterdir())) == 7
     np.testing.assert_allclose(pickle.load(open(d / "rec_0000004_l1.pkl", "rb")), x[4] * 0.5)
+    _assert_python2_era_numpy_can_unpickle((d / "rec_0000004_l1.pkl").read_bytes(), n_objects=1)
     assert [c[:2] for c in calls] == [(3, 0), (3, 6), (1, 12)]
     np.testing.assert_allclose(out["test"][0], x * 0.5)
     n_before = len(calls)
@@ -167,6 +193,7 @@ def test_reconstruct_dataset_cache_layout(tmp_path):
         a, b = pickle.load(f), pickle.load(f)
     np.testing.assert_allclose(a, x, rtol=1e-6)
     assert a.shape == (7, 28, 28, 1) and np.array_equal(b, y)
+    _assert_python2_era_numpy_can_unpickle(open(paths["dev"], "rb").read(), n_objects=2)
     # the classifier-side wrapper forwards to reconstruct with the reference's arguments
     layer = ReconstructionLayer(gan, None, [None, 28, 28, 1], 3)
     np.testing.assert_allclose(layer.fprop(x[:2]), x[:2] * 0.5)

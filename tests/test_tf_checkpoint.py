@@ -117,3 +117,24 @@ def test_corruption_and_errors_are_reported(tmp_path):
     open(prefix + ".index", "wb").write(b"not a table")
     with pytest.raises(T.CheckpointError):
         T.list_variables(prefix)
+
+
+def test_bn_parameters_keep_dims_shapes_load(tmp_path):
+    """tflib Batchnorm saves scale / offset with the keep_dims shape of the moments -- [1,4096] for BN1, [1,1,1,C] for
+    BN2 / BN3 (/root/reference/tflib/ops/batchnorm.py:83-89): a USE_BN checkpoint of the reference must load."""
+    from defensegan_amd.gan import dataset_gan_dict
+    p, t = _ref_style_tensors("mnist", use_bn=True)
+    for full in list(t):
+        leaf = full.split("/")[-1]
+        if leaf.endswith(".scale") or leaf.endswith(".offset"):
+            if full.endswith("/Adam") or full.endswith("/Adam_1"):
+                continue
+            c = t[full].size
+            t[full] = t[full].reshape((1, c) if "BN1" in leaf else (1, 1, 1, c))
+    T.write_checkpoint(str(tmp_path / "GAN.model-1"), t)
+    gan = dataset_gan_dict["mnist"](cfg={"USE_BN": True}, test_mode=True)
+    assert gan.load_generator(str(tmp_path)) is True and gan.initialized
+    for k in p:
+        assert gan._weights[k].shape == p[k].shape and np.array_equal(gan._weights[k], p[k]), k
+    with pytest.raises(ValueError, match="BN2.scale"):
+        gan.set_weights({"Generator.BN2.scale": np.ones((1, 1, 1, 127), np.float32)})
