@@ -8,6 +8,13 @@ step   : one pass of the hot path (dg_reconstruct) over one batch of B synthetic
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+
+--strong: BASELINE configs[4] shape instead -- a step is ONE defended evaluation of a fixed list of 10 000 synthetic
+images (FGSM-like inputs, classifier model A), sharded contiguously over the ranks (gan_defense.shard_range), projected
+in batches, with the single all_gather of (labels, preds, diffs) at the end; images/s = 10 000 / wall ("scaling": "strong").
+
+The timed region carries NO instrumentation.  Per-kernel durations for the roofline leg come from ONE extra, untimed
+step after it, in which every kernel of every GD iteration is bracketed by hipEvents on the launch stream.
 """
 from __future__ import annotations
 
@@ -38,18 +45,42 @@ WORKLOADS = {
 }
 
 
+def build_id():
+    """First 12 hex digits of the SHA-256 over the HIP/C++ sources the loaded library was built from."""
+    from defensegan_amd import build as _b
+    return _b._digest()[:12]
+
+
 def traffic_for(workload, kernel, B, R):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_v5_pmc_traffic.json,
-    built by tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); PMC counters cannot be
-    read from inside this process, so the figure is only reported for the configurations it was collected on
-    (MNIST arch at 2560 rows, CelebA at 1280 rows)."""
-    path = os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be read from inside this process, so
+    the figure comes from a file -- and is quoted ONLY when that file was collected on exactly this build of the kernels
+    (its "build" field equals build_id()) and on this row count; otherwise null."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     key = "mnist" if workload in ("mnist", "fmnist") else workload
     if kernel is None or not os.path.exists(path) or B * R != {"mnist": 2560, "celeba": 1280}.get(key, -1):
-        return None
+        return None, None
     with open(path) as fh:
-        t = json.load(fh).get(key, {})
-    return t.get(kernel, {}).get("bytes_per_launch")
+        doc = json.load(fh)
+    if doc.get("build") != build_id():
+        return None, None
+    return doc.get(key, {}).get(kernel, {}).get("bytes_per_launch"), "profiles/" + TRAFFIC_FILE
+
+
+TRAFFIC_FILE = "r02_pmc_traffic.json"
+
+
+def make_inputs(gan, a, B, rank=0, first_image=0):
+    """The bench's synthetic inputs, resident in HBM: x = clip(G(z_true) + 0.3*sign(noise)), an FGSM-eps-0.3-like
+    perturbation of in-range images (whitebox.py:199).  Both draws are counter-based and keyed by the image index, so the
+    images do not depend on how they are batched or sharded.  Also used by tests/test_gpu_parity_tiers.py."""
+    import torch
+    zt = gan.init_latents(B, seed=1000 + rank, first_row=first_image)
+    x = gan.generate(zt)
+    P = int(np.prod(a.image_dim))
+    rows = (P + a.latent_dim - 1) // a.latent_dim
+    noise = gan.init_latents(B * rows, seed=7 + rank, first_row=first_image * rows, std=1.0).view(B, -1)[:, :P].reshape(x.shape)
+    return torch.clamp(x + 0.3 * torch.sign(noise), a.in_lo, a.in_hi).contiguous()
 
 
 def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
@@ -95,6 +126,45 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
                       "scaled by (2L-1) to L=%d" % (nimg_total, nimg, R, Ls, cores, dt, L)}
 
 
+def roofline_from_profile(prof, workload, B, R, path_tflops):
+    """Per-layer rows + the roofline object of the dominant kernel symbol from the engine's event profile.  Profile
+    entries are "<layer>@<kernel symbol>": per-layer rows for the breakdown, per-symbol groups (what rocprofv3 --stats
+    aggregates) for the roofline."""
+    kernels, groups = [], {}
+    for p in prof:
+        if p["launches"] == 0:
+            continue
+        layer, _, sym = p["name"].partition("@")
+        avg_ms = p["ms"] / p["launches"]
+        tf = (p["flops"] / p["launches"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        kernels.append({"name": layer, "kernel": sym, "launches_sampled": p["launches"],
+                        "avg_us": round(avg_ms * 1e3, 2), "tflops": round(tf, 2)})
+        g = groups.setdefault(sym, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        g["ms"] += p["ms"]; g["flops"] += p["flops"]; g["launches"] += p["launches"]
+    dom = None
+    if groups:
+        sym = max(groups, key=lambda k: groups[k]["ms"])          # dominant kernel = most total time
+        g = groups[sym]
+        dom = {"kernel": sym, "avg_us": round(g["ms"] / g["launches"] * 1e3, 2),
+               "flop_per_launch": g["flops"] / g["launches"],
+               "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2)}
+    traffic, traffic_src = traffic_for(workload, dom["kernel"] if dom else None, B, R)
+    roofline = {
+        "bound": "mfma",
+        "kernel": dom["kernel"] if dom else None,
+        "avg_launch_us": dom["avg_us"] if dom else None,
+        "flop_per_launch": dom["flop_per_launch"] if dom else None,
+        "achieved": dom["tflops"] if dom else round(path_tflops, 2),
+        "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+        "frac": round((dom["tflops"] if dom else path_tflops) / PEAK_FP32_TFLOPS, 4),
+        "traffic": traffic, "traffic_source": traffic_src,
+        "path_achieved": round(path_tflops, 2),
+        "path_frac": round(path_tflops / PEAK_FP32_TFLOPS, 4),
+        "sum_kernel_ms_per_step": round(sum(g["ms"] for g in groups.values()), 3) if groups else None,
+    }
+    return kernels, roofline
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,8 +175,10 @@ def main():
     ap.add_argument("--rec_rr", type=int, default=None)
     ap.add_argument("--rec_iters", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-stride", type=int, default=10,
-                    help="bracket every kernel of each k-th GD iteration with hipEvents (0 = off)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the untimed per-kernel event pass after the timed steps")
+    ap.add_argument("--strong", action="store_true",
+                    help="configs[4] shape: one step = a defended evaluation of --images images sharded over the ranks")
+    ap.add_argument("--images", type=int, default=10000, help="--strong: images in the evaluated list")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
     args = ap.parse_args()
 
@@ -122,9 +194,16 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     arch, wseed, gain, B, R, L = WORKLOADS[args.workload]
+    if args.strong:
+        if args.workload != "mnist":
+            raise SystemExit("--strong is the MNIST configs[4] workload")
+        B = 1250                    # projection batch = the per-GPU shard of 10 000 images at 8 GPUs
     B = args.batch or B
     R = args.rec_rr or R
     L = args.rec_iters or L
@@ -137,34 +216,47 @@ def main():
         k, v = kv.split("=", 1)
         gan.set_option(k, v)
 
-    # synthetic inputs, resident in HBM: x = clip(G(z_true) + 0.3*sign(noise)) (FGSM-eps-0.3-like), per rank
-    zt = gan.init_latents(B, seed=1000 + rank)
-    x = gan.generate(zt)
-    noise = torch.randn(x.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(7 + rank))
-    x = torch.clamp(x + 0.3 * torch.sign(noise), a.in_lo, a.in_hi).contiguous()
-
-    def step(i):
-        # a new batch of images every step: global row index advances, so z0 differs
-        first_row = ((i * world) + rank) * B * R
-        return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
-
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.strong:
+        # ---- configs[4]: a fixed image list, sharded by image; ONE gather of (labels, preds, diffs) per evaluation
+        from defensegan_amd import gan_defense, network_builder as nb
+        n_total = args.images
+        s0, e0 = gan_defense.shard_range(n_total, rank, world)
+        x = torch.cat([make_inputs(gan, a, min(2000, e0 - i), 0, first_image=i) for i in range(s0, e0, 2000)]) \
+            if e0 > s0 else torch.empty((0,) + tuple(a.image_dim), device=dev)
+        clf = nb.model_a()
+        clf._device = local_rank
+        clf.init_like_reference(seed=5)
+        labels = clf.fprop(x)["logits"].argmax(dim=1).cpu().numpy() if e0 > s0 else np.zeros(0, np.int64)
+        result = {}
+
+        def step(i):
+            acc, roc = gan_defense.model_eval_gan_sharded(gan.reconstruct, clf, x, labels, batch_size=B, rec_rr=R,
+                                                          n_total=n_total, seed=2024 + i)
+            result["acc"], result["roc"] = acc, roc
+            return None
+        units_per_step = n_total
+    else:
+        x = make_inputs(gan, a, B, rank)
+
+        def step(i):
+            # a new batch of images every step: global row index advances, so z0 differs
+            first_row = ((i * world) + rank) * B * R
+            return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
+        units_per_step = world * B
+
     for i in range(args.warmup):
         step(i)
     barrier()
-    # Per-kernel durations for the roofline leg are measured LIVE inside the timed region: hipEvents on the launch
-    # stream around every kernel of each k-th GD iteration (k = --profile-stride; ~180 event pairs per step).
-    gan.profile_reset()
-    gan.profile_enable(args.profile_stride)
     t0 = time.perf_counter()
     out = None
     for i in range(args.steps):
         out = step(args.warmup + i)
-    if distributed:
+    if distributed and not args.strong:
         # the path's one exchange: per-image (selected restart, best loss) gathered over RCCL/xGMI
         best = out["loss"].view(B, R).min(dim=1).values
         msg = torch.stack([out["idx"].float(), best], dim=1).contiguous()
@@ -172,66 +264,53 @@ def main():
         dist.all_gather(gathered, msg)
     barrier()
     dt = time.perf_counter() - t0
-    gan.profile_enable(0)
     if distributed:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    prof = gan.profile_read()
+    # ---- untimed: one more step with every kernel of every GD iteration bracketed by hipEvents (rank 0 reports)
+    prof = []
+    if not args.no_profile and not args.strong:
+        gan.profile_reset()
+        gan.profile_enable(1)
+        step(args.warmup + args.steps)
+        torch.cuda.synchronize(dev)
+        gan.profile_enable(0)
+        prof = gan.profile_read()
+
     if rank == 0:
-        images = world * B * args.steps
-        value = images / dt
+        value = units_per_step * args.steps / dt
         flop_img = archs.flop_per_image(a, R, max(L, 1))
         path_tflops = value * flop_img / 1e12 / world           # per GPU
-        # profile entries are "<layer>@<kernel symbol>": per-layer rows for the breakdown, per-symbol groups (what
-        # rocprofv3 --stats aggregates) for the roofline of the dominant kernel
-        kernels, groups = [], {}
-        for p in prof:
-            if p["launches"] == 0:
-                continue
-            layer, _, sym = p["name"].partition("@")
-            avg_ms = p["ms"] / p["launches"]
-            tf = (p["flops"] / p["launches"]) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-            kernels.append({"name": layer, "kernel": sym, "launches_sampled": p["launches"],
-                            "avg_us": round(avg_ms * 1e3, 2), "tflops": round(tf, 2)})
-            g = groups.setdefault(sym, {"ms": 0.0, "flops": 0.0, "launches": 0})
-            g["ms"] += p["ms"]; g["flops"] += p["flops"]; g["launches"] += p["launches"]
-        dom = None
-        if groups:
-            sym = max(groups, key=lambda k: groups[k]["ms"])          # dominant kernel = most total time
-            g = groups[sym]
-            dom = {"kernel": sym, "avg_us": round(g["ms"] / g["launches"] * 1e3, 2),
-                   "flop_per_launch": g["flops"] / g["launches"],
-                   "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2)}
-        roofline = {
-            "bound": "mfma",
-            "kernel": dom["kernel"] if dom else None,
-            "avg_launch_us": dom["avg_us"] if dom else None,
-            "flop_per_launch": dom["flop_per_launch"] if dom else None,
-            "achieved": dom["tflops"] if dom else round(path_tflops, 2),
-            "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": round((dom["tflops"] if dom else path_tflops) / PEAK_FP32_TFLOPS, 4),
-            "traffic": traffic_for(args.workload, dom["kernel"] if dom else None, B, R),
-            "path_achieved": round(path_tflops, 2),
-            "path_frac": round(path_tflops / PEAK_FP32_TFLOPS, 4),
-        }
-        loss = out["loss"].view(B, R).min(dim=1).values
+        kernels, roofline = roofline_from_profile(prof, args.workload, B, R, path_tflops)
+        cfgno = 4 if args.strong else {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload]
+        if args.strong:
+            wl = ("%s whitebox-FGSM-like eps=0.3 evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
+                  "(BASELINE configs[4]); images sharded contiguously over %d rank(s), one all_gather of (labels, preds, "
+                  "diffs)" % (arch, args.images, L, R, B, world))
+        else:
+            wl = ("%s L=%d R=%d batch=%d fp32 (BASELINE configs[%d]); synthetic tflib-init weights gain %.1f, "
+                  "x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B, cfgno, gain))
         res = {
             "metric": "projected images/sec at L=%d,R=%d (%s)" % (L, R, "MNIST 28x28" if a.arch_id == 0 else "CelebA 64x64"),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s L=%d R=%d batch=%d fp32 (BASELINE configs[%d]); synthetic tflib-init weights "
-                                   "gain %.1f, x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B,
-                                                                               {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload], gain),
-                       "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0, "parallelism": "shard%d" % world},
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0,
+                       "parallelism": "shard%d" % world},
+            "build": build_id(),
             "roofline": roofline,
             "kernels": kernels,
-            "mean_best_loss": round(float(loss.mean().item()), 6),
         }
+        if args.strong:
+            res["accuracy"] = round(float(result["acc"]), 4)
+            res["mean_diff"] = round(float(result["roc"][2].mean()), 6)
+        else:
+            loss = out["loss"].view(B, R).min(dim=1).values
+            res["mean_best_loss"] = round(float(loss.mean().item()), 6)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(arch, params, x.cpu().numpy(), R, L)
+            res["cpu_baseline"] = cpu_baseline(arch, params, x[:16].cpu().numpy(), R, L)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()

@@ -107,10 +107,13 @@ def gather_shards(local_rows: np.ndarray, n_total: int, group=None, device=None)
 
 
 def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, batch_size: int, rec_rr: int = 1,
-                           group=None, device=None, **kw):
+                           group=None, device=None, n_total: Optional[int] = None, **kw):
     """Batch-sharded evaluation over a torch.distributed group: every rank evaluates its contiguous shard,
     then ONE all_gather (padded to the largest shard) assembles ``roc_info`` in global image order.
-    Returns ``(accuracy, roc_info)`` identically on every rank."""
+    Returns ``(accuracy, roc_info)`` identically on every rank.
+
+    ``test_images`` / ``test_labels`` hold the WHOLE list (every rank slices its ``shard_range``), or -- when ``n_total`` is
+    given -- only this rank's shard of a list of ``n_total`` images (nothing but the shard needs to exist on a rank)."""
     import torch
     import torch.distributed as dist
 
@@ -118,10 +121,17 @@ def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, ba
         c, n, roc = model_eval_gan(reconstruct, classifier, test_images, test_labels, batch_size, rec_rr, **kw)
         return c / max(n, 1), roc
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    n_total = len(test_images)
+    presharded = n_total is not None
+    if not presharded:
+        n_total = len(test_images)
     s, e = shard_range(n_total, rank, world)
-    c, n, roc = model_eval_gan(reconstruct, classifier, test_images[s:e], _np(test_labels)[s:e], batch_size, rec_rr,
-                               first_image=s, **kw)
+    if presharded:
+        if len(test_images) != e - s:
+            raise ValueError("rank %d holds %d images, its shard of %d is [%d,%d)" % (rank, len(test_images), n_total, s, e))
+        shard_x, shard_y = test_images, _np(test_labels)
+    else:
+        shard_x, shard_y = test_images[s:e], _np(test_labels)[s:e]
+    c, n, roc = model_eval_gan(reconstruct, classifier, shard_x, shard_y, batch_size, rec_rr, first_image=s, **kw)
     cap = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"

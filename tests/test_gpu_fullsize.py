@@ -10,7 +10,7 @@ from tests.helpers import clean_targets, make_gan
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("arch,wseed,B,nb", [("fmnist", 4321, 256, 3), ("celeba", 1234, 128, 1)])
+@pytest.mark.parametrize("arch,wseed,B,nb", [("fmnist", 4321, 256, 16), ("celeba", 1234, 128, 4)])
 def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
     R, L = 10, 200
     a = archs.make_arch(arch)
@@ -42,6 +42,7 @@ def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
     # at the reference's lr = 10 is CHAOTIC (tools/diag_long_horizon.py: fp32 vs fp64 of the same torch code differ by
     # 25-50 % in per-restart loss from L = 20 on, the device path sits closer to fp64 than torch-fp32 does), so a
     # long-horizon value comparison is only meaningful where the loop contracts: lr = 3 for CelebA, lr = 10 for F-MNIST.
+    # (CelebA at the reference's lr = 10 is covered distributionally in test_gpu_parity_tiers.py.)
     from oracle import torch_ref as T
     lr = 3.0 if arch == "celeba" else 10.0
     gan.rec_lr = lr
