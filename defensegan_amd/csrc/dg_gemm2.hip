@@ -1,0 +1,325 @@
+// Position-batched gathered implicit GEMM for gfx950 (MI355X): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+// Second generation of dg_gemm.hip (same arithmetic per output element: one k-ordered fp32 fma chain over
+// (tap, channel), taps in the planner's order).  Covers Linear fwd/bwd and every 5x5 stride-2 transposed conv fwd /
+// backward-to-input of the Defense-GAN generators (reference call sites: tflib/ops/linear.py:129-142,
+// tflib/ops/deconv2d.py:100-117).
+//
+// What changed against the per-position kernel:
+//  * M axis = (latent row, output position) pairs of one tap CLASS (dg_plan.cpp): positions with the same relative tap
+//    pattern share the filter slabs, so an M tile is dense for ANY batch size and every tile of a class has the same K.
+//  * One workgroup = one JOB from a host-built list ordered longest first; the hardware dispatcher is the (dynamic) queue.
+//    Jobs late in the list are the same tiles cut in halves / quarters along M and N (never along K, so every output
+//    element keeps its summation order whatever the batch looks like): big tiles for the MFMA rate, small ones to level
+//    the end of the launch.
+//  * 128x128 tiles (2x2 waves, 64x64 per wave, four independent accumulators): 8 operand lines staged per 64 MFMAs
+//    instead of 8 per 32; operand DMA through buffer_load ... lds with the chunk offset in an SGPR (no address VALU).
+//  * The fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk and pinned there.
+#include <type_traits>
+
+#include "dg_kernels.h"
+
+namespace dg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+
+constexpr int BK = 32;                 // floats per K chunk = one 128-B line per row
+constexpr int ROW_BYTES = BK * 4;
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// LLVM SchedGroupMask bits
+constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSREAD = 0x100;
+
+template <int TM, int TN, int MODE, int FAM>
+__device__ __forceinline__ void run_job(const Gemm2Args& g, const JobDesc jb, char* smem) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;      // waves are 2 x 2, each owns TM x TN 32x32 accumulator tiles
+    constexpr int SA = BM / 32, SB = BN / 32;      // staging slots (one 1 KB wave-instruction each) per wave
+    constexpr int NS = SA + SB;
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    long long tr0 = 0;
+    if (g.trace) tr0 = wall_clock64();
+
+    const ClassDesc cd = g.cls[jb.cls];
+    const int s_cnt = cd.pos_count;
+    const unsigned magic = cd.magic;
+    const int m_valid = jb.m_valid;
+    // M row r of the job -> (latent row n_first + q, position j)
+    auto split = [&](int r, int& q, int& j) {
+        const unsigned jj = (unsigned)(jb.j_first + r);
+        q = magic ? (int)__umulhi(jj, magic) : (int)jj;
+        j = (int)jj - q * s_cnt;
+    };
+
+    // ---- operand descriptors.  A: base = first latent row of the job; per-lane byte offset of its staging rows.
+    const float* a_base = g.A + (long long)jb.n_first * g.a_rowstride;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_base), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, 0x7ffffff0, 0x00020000);
+    unsigned voff_a[SA], voff_w[SB];
+#pragma unroll
+    for (int s = 0; s < SA; ++s) {
+        const int r = (s * 4 + wave) * 8 + (lane >> 3);           // row inside the A tile
+        const int c = (lane & 7) ^ swz(r);                         // source 16-B chunk for LDS slot lane&7
+        const int rc = r < m_valid ? r : m_valid - 1;              // ragged M: clamp loads, mask stores
+        int q, j;
+        split(rc, q, j);
+        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + g.pos_a[cd.pos_begin + j]) * 4u + (unsigned)c * 16u;
+    }
+#pragma unroll
+    for (int s = 0; s < SB; ++s) {
+        const int r = (s * 4 + wave) * 8 + (lane >> 3);           // output column inside the tile
+        const int c = (lane & 7) ^ swz(r);
+        voff_w[s] = (unsigned)((jb.n0 + r) * g.w_rowstride) * 4u + (unsigned)c * 16u;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int chunks_per_tap = g.kch / BK;
+    const int n_taps = cd.nchunks / chunks_per_tap;
+    const int nchunks = cd.nchunks;
+    const TapEntry* taps = g.taps + cd.tap_begin;
+
+    // Staging plan: the slots of chunk c+1 are issued BETWEEN the MFMA groups of chunk c (slot s rides with k-step s % 4).
+    int ld_tap = 0, ld_k = 0;
+    TapEntry te_nxt = n_taps > 0 ? taps[n_taps > 1 ? 1 : 0] : TapEntry{0, 0};
+    const TapEntry te0 = n_taps > 0 ? taps[0] : TapEntry{0, 0};
+    int cur_a = __builtin_amdgcn_readfirstlane(te0.a_off);
+    int cur_w = __builtin_amdgcn_readfirstlane(te0.w_off);
+    int aoff = 0, woff = 0;                    // operand byte offsets of the chunk being staged (SGPRs)
+    auto next_chunk_offsets = [&]() {
+        aoff = (cur_a + ld_k) * 4;
+        woff = (cur_w + ld_k) * 4;
+        ld_k += BK;
+        if (ld_k == g.kch) {
+            ld_k = 0;
+            ++ld_tap;
+            cur_a = __builtin_amdgcn_readfirstlane(te_nxt.a_off);
+            cur_w = __builtin_amdgcn_readfirstlane(te_nxt.w_off);
+            const int nx = ld_tap + 1 < n_taps ? ld_tap + 1 : n_taps - 1;
+            te_nxt = taps[nx];
+        }
+    };
+    auto issue_slot = [&](int s, char* stage_base) {
+        if (s < SA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, DG_LDS_PTR(stage_base + (s * 4 + wave) * 1024), 16,
+                                                     voff_a[s < SA ? s : 0], aoff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, DG_LDS_PTR(stage_base + BM * ROW_BYTES + ((s - SA) * 4 + wave) * 1024), 16,
+                                                     voff_w[s >= SA ? s - SA : 0], woff, 0, 0);
+    };
+
+    // fragment read addresses (byte offsets inside a stage), fixed per thread
+    const int frow = lane & 31;
+    const int fh = lane >> 5;
+    int a_rd[TM], b_rd[TN], a_sw[TM], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * (BM / 2) + i * 32 + frow;
+        a_rd[i] = r * ROW_BYTES;
+        a_sw[i] = swz(r);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * (BN / 2) + j * 32 + frow;
+        b_rd[j] = BM * ROW_BYTES + r * ROW_BYTES;
+        b_sw[j] = swz(r);
+    }
+
+    // Output rows of this lane in the epilogue: pass p of tile row-block i covers tile row wm*BM/2 + i*32 + p*8 + (lane >> 3),
+    // columns 4*(lane & 7)..+3 of each 32-column block.
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    float* out_base = g.Out + (long long)jb.n_first * g.out_rowstride + jb.n0;
+    unsigned orow[TM][4];                          // float offset of the row inside the job's output window
+    bool ovalid[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = wm * (BM / 2) + i * 32 + p * 8 + er;
+            ovalid[i][p] = r < m_valid;
+            int q, j;
+            split(ovalid[i][p] ? r : 0, q, j);
+            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + g.pos_out[cd.pos_begin + j]);
+        }
+
+    // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk.
+    f32x4 oldv[TM][TN][4];
+    auto prefetch_mask = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = wn * (BN / 2) + j * 32 + ec;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ovalid[i][p]) v = *reinterpret_cast<const f32x4*>(out_base + orow[i][p] + col);
+                    oldv[i][j][p] = v;
+                }
+        }
+    };
+    if (MODE == EPI_MASK && nchunks == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) oldv[i][j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (nchunks > 0) {
+        next_chunk_offsets();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) issue_slot(s, smem);
+    }
+    // One K chunk: wait for its operands, then 4 k-steps; the fragments of k-step kk+1 are read before the MFMAs of kk, and
+    // the next chunk's DMA (or, in the LAST chunk of a ReluGrad tile, the gate prefetch) rides between the MFMA groups.
+    auto chunk_body = [&](int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // chunk c landed for every wave; stage (c+1)&1 is free
+        if constexpr (!LAST) next_chunk_offsets();
+        const char* st = smem + (c & 1) * STAGE_BYTES;
+        char* nx = smem + ((c + 1) & 1) * STAGE_BYTES;
+        f32x4 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((fh ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((fh ^ b_sw[j]) << 4));
+        __builtin_amdgcn_sched_group_barrier(SG_DSREAD, TM + TN, 0);     // the k-step 0 fragments
+        auto kstep = [&](auto kk_tag) {
+            constexpr int kk = decltype(kk_tag)::value;
+            constexpr int cur = kk & 1, nxt = cur ^ 1;
+            if constexpr (kk < 3) {                // fragments of k-step kk+1 while kk computes
+                const int chunk = (kk + 1) * 2 + fh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[nxt][i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((chunk ^ a_sw[i]) << 4));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[nxt][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((chunk ^ b_sw[j]) << 4));
+            }
+            constexpr int per_kk = (NS + 3) / 4;   // DMA slots riding with a k-step
+            constexpr int first = kk * per_kk;
+            constexpr int slots_here = LAST ? 0 : (first + per_kk <= NS ? per_kk : (NS > first ? NS - first : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
+                if constexpr (!LAST) {
+                    if (e < slots_here) issue_slot(first + e, nx);        // slot first+e rides behind MFMA group e
+                } else if constexpr (MODE == EPI_MASK) {
+                    if (kk == 0 && e == 0) prefetch_mask();
+                }
+            }
+            // pin the order: [fragment reads of kk+1] ([MFMA group] [DMA]) x slots_here [remaining MFMAs]
+            if constexpr (kk < 3) __builtin_amdgcn_sched_group_barrier(SG_DSREAD, TM + TN, 0);
+            if constexpr (slots_here >= 1) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            if constexpr (slots_here >= 2) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            if constexpr (slots_here >= 3) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN * (4 - (slots_here > 3 ? 3 : slots_here)), 0);
+        };
+        kstep(std::integral_constant<int, 0>());
+        kstep(std::integral_constant<int, 1>());
+        kstep(std::integral_constant<int, 2>());
+        kstep(std::integral_constant<int, 3>());
+    };
+    for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::false_type());
+    if (nchunks > 0) chunk_body(nchunks - 1, std::true_type());
+
+    if (g.trace && tid == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        long long* t = g.trace + (long long)blockIdx.x * 4;
+        t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
+    }
+    // ---- epilogue: each 32x32 accumulator tile is transposed through this wave's 4 KB slice of the stage the last chunk
+    // did NOT use, so that a lane owns 4 consecutive channels of one row: b128 stores (and b128 gate loads).
+    float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + ec;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[i][j][e];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = v[q] + bv[q];
+                    if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
+                    if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
+                    v[q] = t;
+                }
+                if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
+            }
+        }
+    }
+}
+
+// FAM 0: layers with >= 128 output columns: 128x128 / 64x128 / 64x64.  FAM 1: 64-column layers: 128x64 / 64x64.
+template <int FAM, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_batched_kernel(Gemm2Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const JobDesc jb = g.jobs[blockIdx.x];
+    const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
+    if constexpr (FAM == 0) {
+        if (shape == 0) run_job<2, 2, MODE, FAM>(g, jb, smem);
+        else if (shape == 1) run_job<1, 2, MODE, FAM>(g, jb, smem);
+        else run_job<1, 1, MODE, FAM>(g, jb, smem);
+    } else {
+        if (shape == 0) run_job<2, 1, MODE, FAM>(g, jb, smem);
+        else run_job<1, 1, MODE, FAM>(g, jb, smem);
+    }
+}
+
+template <int FAM, int MODE>
+void launch_fm(const Gemm2Args& a, hipStream_t s) {
+    const int lds = FAM == 0 ? 2 * (128 + 128) * ROW_BYTES : 2 * (128 + 64) * ROW_BYTES;
+    static PerDeviceOnce attr;
+    if (attr.need(lds))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
+}
+
+template <int FAM>
+void launch_f(const Gemm2Args& a, hipStream_t s) {
+    switch (a.mode) {
+        case EPI_STORE: launch_fm<FAM, EPI_STORE>(a, s); break;
+        case EPI_BIAS: launch_fm<FAM, EPI_BIAS>(a, s); break;
+        case EPI_BIAS_RELU: launch_fm<FAM, EPI_BIAS_RELU>(a, s); break;
+        default: launch_fm<FAM, EPI_MASK>(a, s); break;
+    }
+}
+
+}  // namespace
+
+void launch_gemm2(int family, const Gemm2Args& a, hipStream_t s) {
+    if (a.n_jobs <= 0) return;
+    if (family == 0) launch_f<0>(a, s); else launch_f<1>(a, s);
+}
+
+}  // namespace dg

@@ -68,6 +68,31 @@ void launch_gemm(int tile, const GemmArgs& a, int n_pos, hipStream_t s);
 int gemm_tile_bm(int tile);
 int gemm_tile_bn(int tile);
 
+// ---- position-batched gathered implicit GEMM (dg_gemm2.hip) -------------------------------------
+// Same contraction, M axis = (latent row, output position) pairs of one tap class (dg_types.h), one workgroup per JobDesc.
+//   Out[n, pos_out[j] + n0 + c] = epi( sum_{t in taps(class)} sum_{k < kch} A[n*a_rowstride + pos_a[j] + a_off(t) + k]
+//                                                                         * W[w_off(t) + (n0 + c)*w_rowstride + k] )
+struct Gemm2Args {
+    const float* A;
+    const float* W;
+    float* Out;
+    const float* bias;
+    const JobDesc* jobs;
+    const ClassDesc* cls;
+    const TapEntry* taps;
+    const int* pos_a;        // per position: float offset of its input base inside an A row
+    const int* pos_out;      // per position: float offset inside an output row
+    long long a_rowstride;
+    long long out_rowstride;
+    int w_rowstride;
+    int kch;                 // K extent per tap, multiple of 32
+    int mode;                // EpiMode
+    int n_jobs;
+    long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
+};
+// family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
+void launch_gemm2(int family, const Gemm2Args& a, hipStream_t s);
+
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
 // dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.
 struct MnistTailArgs {

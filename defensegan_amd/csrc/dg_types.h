@@ -15,4 +15,27 @@ struct TapEntry {
     int w_off;           // float offset into the weight buffer
 };
 
+
+// ---- position-batched plan (dg_gemm.hip, second generation) -----------------------------------
+// Output positions whose valid taps are the same relative pattern form a CLASS; inside a class the GEMM's M axis is the
+// list of (latent row n, position j) pairs, m = n * pos_count + j, so an M tile of any height is dense whatever the batch
+// size, every tile of a class has the same K, and the filter slabs of a tap are shared by all its rows.
+struct ClassDesc {
+    int pos_begin;       // first entry of this class in the position tables
+    int pos_count;       // s: positions in the class
+    int tap_begin;       // first entry of this class in the tap table (a_off relative to the row's pos_a base, >= 0)
+    int nchunks;         // K chunks (32 floats each) of every tile of the class = taps * kch / 32
+    unsigned magic;      // ceil(2^32 / s) for the n = m / s split (0 when s == 1)
+    int pad[3];
+};
+struct JobDesc {         // one workgroup = one job: (class, M range, column range, tile shape)
+    int cls;
+    int shape;           // 0 = full tile, 1 = half (M halved), 2 = quarter (M and N halved); same arithmetic per element
+    int n0;              // first output column
+    int n_first;         // latent row of the job's first M row
+    int j_first;         // position index (inside the class) of the job's first M row
+    int m_valid;         // valid M rows of the job (<= tile height)
+    int pad[2];
+};
+
 }  // namespace dg

@@ -41,7 +41,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 try:
     R = 3
     gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=8)
-    x = np.asarray(gan.generate(synth.make_z(64, 128, seed=4)).cpu().numpy())
+    x = np.asarray(gan.generate(synth.make_z(64, 128, seed=4)))
     x = synth.adversarial(x, 0.3, 0.0, 1.0, seed=5)
     clf = nb.model_a(nb_filters=8)
     clf.init_like_reference(seed=6)
