@@ -76,12 +76,27 @@ struct GemmSchedule {
     unsigned* d_list = nullptr;    // [n_pos * n_mtiles]
 };
 
+// Job list of a position-batched launch (dg_gemm2.hip), one per row count a layer has been run with.
+struct JobList {
+    int n_rows = 0, n_jobs = 0, min_level = 0;
+    double predicted_us = 0.0;
+    dg::JobDesc* d_jobs = nullptr;
+};
+
 struct GemmOp {
     std::string name;
     dg::LayerPlan plan;
     dg::PosEntry* d_pos = nullptr;
     dg::TapEntry* d_taps = nullptr;
     std::vector<GemmSchedule> sched;
+    // position-batched form
+    dg::BatchedPlan bplan;
+    int family = 0;
+    dg::ClassDesc* d_cls = nullptr;
+    dg::TapEntry* d_btaps = nullptr;
+    int* d_pos_a = nullptr;
+    int* d_pos_out = nullptr;
+    std::vector<JobList> jobs;
     int tile = 0;
     int mode = 0;
     const float* W = nullptr;
@@ -124,6 +139,13 @@ struct dg_handle {
     int lds_pad = 0;
     int persistent = 1;            // balanced persistent tile lists (dg_gemm.hip): 0 = never, 1 = where measured to pay, 2 = every layer
     int persist_wgs = 0;           // resident workgroups per CU in persistent mode, 0 = by the tile's LDS footprint
+    int gemm2 = 1;                 // 1 = position-batched GEMM (dg_gemm2.hip), 0 = per-position kernel (dg_gemm.hip)
+    double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
+    int job_slots_per_cu[2][3] = {{2, 3, 5}, {3, 5, 5}};   // resident workgroups per CU by (family, smallest level in the list)
+    int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
+    dg::JobModel job_model;
+    long long* d_job_trace = nullptr;
+    std::string job_trace_op;
     int tail_dbg = 0;
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
@@ -256,6 +278,34 @@ const GemmSchedule* get_schedule(GemmOp& op, int tile, int n_mtiles, int grid) {
     return &op.sched.back();
 }
 
+void free_batched(GemmOp& op) {
+    for (auto& jl : op.jobs)
+        if (jl.d_jobs) (void)hipFree(jl.d_jobs);
+    op.jobs.clear();
+    if (op.d_cls) { (void)hipFree(op.d_cls); op.d_cls = nullptr; }
+    if (op.d_btaps) { (void)hipFree(op.d_btaps); op.d_btaps = nullptr; }
+    if (op.d_pos_a) { (void)hipFree(op.d_pos_a); op.d_pos_a = nullptr; }
+    if (op.d_pos_out) { (void)hipFree(op.d_pos_out); op.d_pos_out = nullptr; }
+}
+
+// `base` = the layer planned with one PosEntry per position (bn == ncols)
+int upload_batched(GemmOp& op, const dg::LayerPlan& base) {
+    free_batched(op);
+    op.bplan = dg::make_batched(base);
+    op.family = (base.ncols % 128 == 0) ? 0 : 1;
+    const dg::BatchedPlan& b = op.bplan;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
+        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+        return e;
+    };
+    HIP_TRY(up((void**)&op.d_cls, b.cls.data(), b.cls.size() * sizeof(dg::ClassDesc)));
+    HIP_TRY(up((void**)&op.d_btaps, b.taps.data(), b.taps.size() * sizeof(dg::TapEntry)));
+    HIP_TRY(up((void**)&op.d_pos_a, b.pos_a.data(), b.pos_a.size() * sizeof(int)));
+    HIP_TRY(up((void**)&op.d_pos_out, b.pos_out.data(), b.pos_out.size() * sizeof(int)));
+    return DG_OK;
+}
+
 int upload_plan(GemmOp& op) {
     free_schedules(op);
     if (op.d_pos) { (void)hipFree(op.d_pos); op.d_pos = nullptr; }
@@ -318,6 +368,8 @@ int build_plans(dg_handle* h) {
         op.mode = h->use_bn ? dg::EPI_BIAS : dg::EPI_BIAS_RELU;
         int rc = upload_plan(op);
         if (rc) return rc;
+        rc = upload_batched(op, dg::plan_linear_fwd(h->latent, h->lin_out, h->lin_out));
+        if (rc) return rc;
     }
     {
         GemmOp& op = h->B1;
@@ -327,6 +379,8 @@ int build_plans(dg_handle* h) {
         op.mode = dg::EPI_STORE;
         int rc = upload_plan(op);
         if (rc) return rc;
+        rc = upload_batched(op, dg::plan_linear_bwd(h->latent, h->lin_out, h->nsplit, h->latent));
+        if (rc) return rc;
     }
     const int nd = (int)h->dec.size();
     for (auto* v : {&h->Fd, &h->Bd})
@@ -334,6 +388,7 @@ int build_plans(dg_handle* h) {
             if (o.d_pos) (void)hipFree(o.d_pos);
             if (o.d_taps) (void)hipFree(o.d_taps);
             free_schedules(o);
+            free_batched(o);
         }
     h->Fd.assign(nd - 1, GemmOp());
     h->Bd.assign(nd - 1, GemmOp());
@@ -351,6 +406,9 @@ int build_plans(dg_handle* h) {
             op.mode = out.has_bn ? dg::EPI_BIAS : (s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS);
             int rc = upload_plan(op);
             if (rc) return rc;
+            rc = upload_batched(op, dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin,
+                                                        s.cout, s.cout));
+            if (rc) return rc;
         }
         {
             GemmOp& op = h->Bd[d];
@@ -362,6 +420,11 @@ int build_plans(dg_handle* h) {
             if (in.pitch > in.valid) dg::plan_add_zero_positions(op.plan, in.valid, in.pitch, s.cin);
             op.mode = dg::EPI_MASK;      // every backward output lands on a ReLU activation (h1, h2, h3)
             int rc = upload_plan(op);
+            if (rc) return rc;
+            dg::LayerPlan base = dg::plan_deconv_bwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin,
+                                                     s.cout, s.cin);
+            if (in.pitch > in.valid) dg::plan_add_zero_positions(base, in.valid, in.pitch, s.cin);
+            rc = upload_batched(op, base);
             if (rc) return rc;
         }
     }
@@ -411,7 +474,70 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
+// Job list of `op` for this row count (built once, kept on the device).
+const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows) {
+    for (const auto& jl : op.jobs)
+        if (jl.n_rows == n_rows) return &jl;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    // A list that starts with full tiles leaves room for 2 (family 0) / 3 (family 1) workgroups per CU; lists cut to halves or
+    // quarters from the start need less LDS and registers (dg_gemm2.hip, MINLEVEL) and get more slots: the candidate with the
+    // smallest simulated makespan wins (small launches prefer many small jobs, large ones whole tiles).
+    JobList jl;
+    jl.n_rows = n_rows;
+    std::vector<dg::JobDesc> jobs;
+    const int n_levels = op.family == 0 ? 3 : 2;
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        if (h->job_min_level >= 0 && lvl != h->job_min_level && !(h->job_min_level >= n_levels && lvl == n_levels - 1)) continue;
+        double t = 0.0;
+        std::vector<dg::JobDesc> cand = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl],
+                                                       h->job_slack, h->job_model, &t, lvl);
+        if (jobs.empty() || t < jl.predicted_us) { jobs.swap(cand); jl.predicted_us = t; jl.min_level = lvl; }
+    }
+    jl.n_jobs = (int)jobs.size();
+    if (hipMalloc(&jl.d_jobs, (jobs.size() + 1) * sizeof(dg::JobDesc)) != hipSuccess) return nullptr;
+    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(jl.d_jobs);
+        return nullptr;
+    }
+    if (op.jobs.size() >= 16) {                 // callers with many distinct batch sizes: keep the table bounded
+        (void)hipFree(op.jobs.front().d_jobs);
+        op.jobs.erase(op.jobs.begin());
+    }
+    op.jobs.push_back(jl);
+    return &op.jobs.back();
+}
+
+bool run_gemm2(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    const JobList* jl = get_jobs(h, op, n_rows);
+    if (!jl) return false;
+    dg::Gemm2Args a;
+    a.A = A;
+    a.W = op.W;
+    a.Out = Out;
+    a.bias = op.bias;
+    a.jobs = jl->d_jobs;
+    a.cls = op.d_cls;
+    a.taps = op.d_btaps;
+    a.pos_a = op.d_pos_a;
+    a.pos_out = op.d_pos_out;
+    a.a_rowstride = op.bplan.a_rowstride;
+    a.out_rowstride = op.bplan.out_rowstride;
+    a.w_rowstride = op.bplan.w_rowstride;
+    a.kch = op.bplan.kch;
+    a.mode = op.mode;
+    a.n_jobs = jl->n_jobs;
+    a.min_level = jl->min_level;
+    a.trace = (h->d_job_trace && op.name == h->job_trace_op) ? h->d_job_trace : nullptr;
+    char sym[64];
+    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d>", op.family, op.mode);
+    ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
+    dg::launch_gemm2(op.family, a, s);
+    return true;
+}
+
 void run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    if (h->gemm2 && run_gemm2(h, op, A, Out, n_rows, s, prof)) return;
     dg::GemmArgs a;
     a.A = A;
     a.W = op.W;
@@ -707,6 +833,7 @@ int dg_destroy(dg_handle* h) {
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
     if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
+    if (h->d_job_trace) (void)hipFree(h->d_job_trace);
     if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
         if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
@@ -721,6 +848,7 @@ int dg_destroy(dg_handle* h) {
         if (op.d_taps) (void)hipFree(op.d_taps);
         op.d_pos = nullptr; op.d_taps = nullptr;
         free_schedules(op);
+        free_batched(op);
     };
     frop(h->F1); frop(h->B1);
     for (auto& o : h->Fd) frop(o);
@@ -1010,6 +1138,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
     else if (w == "clk" && h->d_clk) { src = reinterpret_cast<const float*>(h->d_clk); avail = 4; }
+    else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = 65536 * 4 * 2; }
     else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
@@ -1076,6 +1205,33 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "tail_dbg") {
         h->tail_dbg = atoi(value);
+        return DG_OK;
+    }
+    if (k == "gemm2") {
+        h->gemm2 = atoi(value) ? 1 : 0;
+        return DG_OK;
+    }
+    if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
+        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level") {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        const double v = atof(value);
+        if (k == "jobs.slack") h->job_slack = v;
+        else if (k == "jobs.slots0") h->job_slots_per_cu[0][0] = (int)v > 0 ? (int)v : 1;
+        else if (k == "jobs.slots1") h->job_slots_per_cu[1][0] = (int)v > 0 ? (int)v : 1;
+        else if (k == "jobs.min_level") h->job_min_level = (int)v;
+        else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
+        else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
+        for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
+        for (auto* vec : {&h->Fd, &h->Bd})
+            for (auto& op : *vec) { for (auto& jl : op.jobs) (void)hipFree(jl.d_jobs); op.jobs.clear(); }
+        return DG_OK;
+    }
+    if (k == "job_trace") {      // value = op name ("F2"); read back with dg_debug_read("job_trace") (int64 viewed as floats)
+        HIP_TRY(hipSetDevice(h->device));
+        if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)65536 * 4 * sizeof(long long)));
+        HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)65536 * 4 * sizeof(long long)));
+        h->job_trace_op = value;
         return DG_OK;
     }
     if (k == "persistent") {

@@ -26,6 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+int gemm2_lds_bytes(int family, int min_level);
+
 namespace {
 
 constexpr int BK = 32;                 // floats per K chunk = one 128-B line per row
@@ -36,7 +38,8 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 // LLVM SchedGroupMask bits
 constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSREAD = 0x100;
 
-template <int TM, int TN, int MODE, int FAM>
+// (FAM, TAG only make every call site its own specialization: hipcc's host pass rejects a second reference to one)
+template <int TM, int TN, int MODE, int FAM, int TAG>
 __device__ __forceinline__ void run_job(const Gemm2Args& g, const JobDesc jb, char* smem) {
     constexpr int BM = 64 * TM, BN = 64 * TN;      // waves are 2 x 2, each owns TM x TN 32x32 accumulator tiles
     constexpr int SA = BM / 32, SB = BN / 32;      // staging slots (one 1 KB wave-instruction each) per wave
@@ -279,30 +282,45 @@ __device__ __forceinline__ void run_job(const Gemm2Args& g, const JobDesc jb, ch
     }
 }
 
-// FAM 0: layers with >= 128 output columns: 128x128 / 64x128 / 64x64.  FAM 1: 64-column layers: 128x64 / 64x64.
-template <int FAM, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_batched_kernel(Gemm2Args g) {
+// FAM 0: layers with >= 128 output columns: job shapes 128x128 / 64x128 / 64x64.  FAM 1: 64-column layers: 128x64 / 64x64.
+// MINLEVEL = the smallest shape code in the launch's job list: a list without full tiles needs less LDS and fewer
+// registers, so more workgroups are resident per CU (launches too small to fill the chip with big tiles).
+template <int FAM, int MODE, int MINLEVEL>
+__global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (FAM == 0 && MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(Gemm2Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const JobDesc jb = g.jobs[blockIdx.x];
     const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
     if constexpr (FAM == 0) {
-        if (shape == 0) run_job<2, 2, MODE, FAM>(g, jb, smem);
-        else if (shape == 1) run_job<1, 2, MODE, FAM>(g, jb, smem);
-        else run_job<1, 1, MODE, FAM>(g, jb, smem);
+        if constexpr (MINLEVEL <= 0) {
+            if (shape == 0) { run_job<2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        if constexpr (MINLEVEL <= 1) {
+            if (shape == 1) { run_job<1, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
     } else {
-        if (shape == 0) run_job<2, 1, MODE, FAM>(g, jb, smem);
-        else run_job<1, 1, MODE, FAM>(g, jb, smem);
+        if constexpr (MINLEVEL <= 0) {
+            if (shape == 0) { run_job<2, 1, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
     }
+}
+
+template <int FAM, int MODE, int MINLEVEL>
+void launch_fml(const Gemm2Args& a, hipStream_t s) {
+    const int lds = gemm2_lds_bytes(FAM, MINLEVEL);
+    static PerDeviceOnce attr;
+    if (attr.need(lds))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE, MINLEVEL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
 }
 
 template <int FAM, int MODE>
 void launch_fm(const Gemm2Args& a, hipStream_t s) {
-    const int lds = FAM == 0 ? 2 * (128 + 128) * ROW_BYTES : 2 * (128 + 64) * ROW_BYTES;
-    static PerDeviceOnce attr;
-    if (attr.need(lds))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
+    if (a.min_level <= 0) launch_fml<FAM, MODE, 0>(a, s);
+    else if (FAM == 0 && a.min_level == 1) launch_fml<FAM, MODE, 1>(a, s);
+    else launch_fml<FAM, MODE, FAM == 0 ? 2 : 1>(a, s);
 }
 
 template <int FAM>
@@ -316,6 +334,12 @@ void launch_f(const Gemm2Args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// dynamic LDS of a launch: two stages of the largest job shape in its list
+int gemm2_lds_bytes(int family, int min_level) {
+    const int rows = family == 0 ? (min_level <= 0 ? 256 : min_level == 1 ? 192 : 128) : (min_level <= 0 ? 192 : 128);
+    return 2 * rows * ROW_BYTES;
+}
 
 void launch_gemm2(int family, const Gemm2Args& a, hipStream_t s) {
     if (a.n_jobs <= 0) return;

@@ -88,10 +88,12 @@ struct Gemm2Args {
     int kch;                 // K extent per tap, multiple of 32
     int mode;                // EpiMode
     int n_jobs;
+    int min_level;           // smallest shape code among the jobs (0 = the list holds full tiles)
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 };
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
 void launch_gemm2(int family, const Gemm2Args& a, hipStream_t s);
+int gemm2_lds_bytes(int family, int min_level);
 
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
 // dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.

@@ -1,6 +1,10 @@
 #include "dg_plan.h"
 
 #include <algorithm>
+#include <functional>
+#include <map>
+#include <queue>
+#include <utility>
 
 namespace dg {
 
@@ -112,6 +116,179 @@ void plan_add_zero_positions(LayerPlan& p, int used, int pitch, int ncols) {
             if (i < used && j < used) continue;
             for (int n0 = 0; n0 < ncols; n0 += p.bn) p.pos.push_back(PosEntry{(i * pitch + j) * ncols, n0, 0, 0});
         }
+}
+
+
+BatchedPlan make_batched(const LayerPlan& p) {
+    BatchedPlan b;
+    b.name = p.name;
+    b.a_rowstride = p.a_rowstride;
+    b.out_rowstride = p.out_rowstride;
+    b.w_rowstride = p.w_rowstride;
+    b.kch = p.kch;
+    b.ncols = p.ncols;
+    b.macs_per_row = p.macs_per_row;
+    typedef std::vector<std::pair<int, int>> Sig;            // (a_off relative to the smallest one, w_off) per tap, in order
+    std::map<Sig, int> index;
+    std::vector<Sig> sigs;
+    std::vector<std::vector<std::pair<int, int>>> members;   // per class: (pos_a, pos_out) of its positions
+    for (const PosEntry& pe : p.pos) {
+        int a_min = 0;
+        for (int t = 0; t < pe.tap_count; ++t) {
+            const int a = p.taps[pe.tap_begin + t].a_off;
+            if (t == 0 || a < a_min) a_min = a;
+        }
+        Sig sig;
+        for (int t = 0; t < pe.tap_count; ++t)
+            sig.push_back(std::make_pair(p.taps[pe.tap_begin + t].a_off - a_min, p.taps[pe.tap_begin + t].w_off));
+        auto it = index.find(sig);
+        int c;
+        if (it == index.end()) {
+            c = (int)sigs.size();
+            index[sig] = c;
+            sigs.push_back(sig);
+            members.push_back({});
+        } else {
+            c = it->second;
+        }
+        members[c].push_back(std::make_pair(a_min, pe.out_off));
+    }
+    std::vector<int> order(sigs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sigs[x].size() > sigs[y].size(); });
+    const int cpt = p.kch / 32;
+    for (int c : order) {
+        ClassDesc cd = {};
+        cd.pos_begin = (int)b.pos_a.size();
+        cd.pos_count = (int)members[c].size();
+        cd.tap_begin = (int)b.taps.size();
+        cd.nchunks = (int)sigs[c].size() * cpt;
+        cd.magic = cd.pos_count == 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned)cd.pos_count - 1) / (unsigned)cd.pos_count);
+        for (const auto& m : members[c]) { b.pos_a.push_back(m.first); b.pos_out.push_back(m.second); }
+        for (const auto& t : sigs[c]) b.taps.push_back(TapEntry{t.first, t.second});
+        b.cls.push_back(cd);
+    }
+    return b;
+}
+
+namespace {
+
+const int kFullBM[2] = {128, 128};
+const int kFullBN[2] = {128, 64};
+
+int shape_bm(int shape) { return shape == 0 ? 128 : 64; }
+int shape_bn(int family, int shape) { return family == 0 ? (shape == 2 ? 64 : 128) : 64; }
+
+double job_us(const BatchedPlan& p, const JobDesc& j, int family, int slots, const JobModel& m) {
+    // a job occupies its tile's full MFMA footprint whatever m_valid is
+    const double flop = 2.0 * p.cls[j.cls].nchunks * 32.0 * shape_bm(j.shape) * shape_bn(family, j.shape);
+    return flop / (m.rate[family][j.shape] * 1e6 / slots) + m.fixed_us[family][j.shape];
+}
+
+// One pass of "longest first with cutting on demand": jobs are handed to the earliest free of `slots` servers in descending
+// cost; a job that would end after `target` is cut in two along M (then along N) and its pieces go back into the pool, so
+// the launch starts with whole tiles and ends with small ones.  The order of assignment is the dispatch order.
+std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int family, int slots, double slack, int min_level,
+                                     const JobModel& model) {
+    const int BM = kFullBM[family], BN = kFullBN[family];
+    const int max_level = family == 0 ? 2 : 1;
+    if (min_level > max_level) min_level = max_level;
+    struct Piece { double us; int cls; int level; long long m0; int rows; int n0; unsigned seq; };
+    auto cmp = [](const Piece& a, const Piece& b) { return a.us < b.us || (a.us == b.us && a.seq > b.seq); };
+    std::priority_queue<Piece, std::vector<Piece>, decltype(cmp)> pool(cmp);
+    unsigned seq = 0;
+    double total = 0.0;
+    auto cost = [&](int cls, int level) {
+        JobDesc j = {};
+        j.cls = cls; j.shape = level;
+        return job_us(p, j, family, slots, model);
+    };
+    for (int c = 0; c < (int)p.cls.size(); ++c) {
+        const long long M = (long long)n_rows * p.cls[c].pos_count;
+        for (long long m0 = 0; m0 < M; m0 += BM)
+            for (int n0 = 0; n0 < p.ncols; n0 += BN) {
+                const int rows = (int)std::min<long long>(BM, M - m0);
+                const int level = std::max(min_level, rows <= BM / 2 ? 1 : 0);
+                const int bm = shape_bm(level), bn = shape_bn(family, level);
+                for (int r0 = 0; r0 < rows; r0 += bm)
+                    for (int c0 = 0; c0 < BN; c0 += bn) {
+                        Piece pc = {cost(c, level), c, level, m0 + r0, std::min(bm, rows - r0), n0 + c0, seq++};
+                        total += pc.us;
+                        pool.push(pc);
+                    }
+            }
+    }
+    const double target = slack >= 1e20 ? 1e300 : total / slots * slack;
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < slots; ++i) free_at.push(0.0);
+    std::vector<JobDesc> out;
+    while (!pool.empty()) {
+        Piece pc = pool.top();
+        pool.pop();
+        const double t0 = free_at.top();
+        if (t0 + pc.us > target && pc.level < max_level) {
+            // cut: level 0 -> two halves along M; level 1 -> two quarters along N (family 0 only)
+            if (pc.level == 0) {
+                const int h = BM / 2;
+                for (int r0 = 0; r0 < pc.rows; r0 += h) {
+                    Piece q = {cost(pc.cls, 1), pc.cls, 1, pc.m0 + r0, std::min(h, pc.rows - r0), pc.n0, seq++};
+                    pool.push(q);
+                }
+            } else {
+                for (int c0 = 0; c0 < BN; c0 += 64) {
+                    Piece q = {cost(pc.cls, 2), pc.cls, 2, pc.m0, pc.rows, pc.n0 + c0, seq++};
+                    pool.push(q);
+                }
+            }
+            continue;
+        }
+        free_at.pop();
+        free_at.push(t0 + pc.us);
+        const int s = p.cls[pc.cls].pos_count;
+        JobDesc j = {};
+        j.cls = pc.cls;
+        j.shape = pc.level;
+        j.n0 = pc.n0;
+        j.n_first = (int)(pc.m0 / s);
+        j.j_first = (int)(pc.m0 % s);
+        j.m_valid = pc.rows;
+        out.push_back(j);
+    }
+    return out;
+}
+
+}  // namespace
+
+double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model) {
+    std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
+    for (int i = 0; i < slots; ++i) free_at.push(0.0);
+    double end = 0.0;
+    for (const JobDesc& j : jobs) {
+        const double t = free_at.top() + job_us(p, j, family, slots, model);
+        free_at.pop();
+        free_at.push(t);
+        if (t > end) end = t;
+    }
+    return end;
+}
+
+std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, int slots, double slack, const JobModel& model,
+                                double* predicted_us, int min_level) {
+    std::vector<JobDesc> best;
+    double best_t = 0.0;
+    if (slack > 0.0) {
+        best = jobs_for_target(p, n_rows, family, slots, slack, min_level, model);
+        best_t = simulate_jobs(p, best, family, slots, model);
+    } else {
+        const double ladder[] = {1e30, 1.0, 1.02, 1.04, 1.07, 1.1, 1.15};
+        for (double a : ladder) {
+            std::vector<JobDesc> j = jobs_for_target(p, n_rows, family, slots, a, min_level, model);
+            const double t = simulate_jobs(p, j, family, slots, model);
+            if (best.empty() || t < best_t) { best.swap(j); best_t = t; }
+        }
+    }
+    if (predicted_us) *predicted_us = best_t;
+    return best;
 }
 
 }  // namespace dg

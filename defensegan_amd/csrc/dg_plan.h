@@ -37,4 +37,41 @@ LayerPlan plan_deconv_bwd(int h_in, int out_pitch, int e_out, int a_pitch, int c
 // the epilogue then writes zeros there (gradient of the MNIST crop = zero padding, needed by BN statistics).
 void plan_add_zero_positions(LayerPlan& p, int used, int pitch, int ncols);
 
+
+// ---- position-batched form (dg_gemm2.hip) -------------------------------------------------------
+// The same layer regrouped: output positions whose valid taps form the same RELATIVE pattern (same filter taps, same
+// input offsets relative to the position) are one class; the tap order inside a class is the per-position order above, so
+// every output element keeps its summation order.
+struct BatchedPlan {
+    std::string name;
+    std::vector<ClassDesc> cls;    // sorted by descending K
+    std::vector<TapEntry> taps;    // per class: a_off >= 0 relative to pos_a of the row's position, w_off as above
+    std::vector<int> pos_a;        // per position (class-major): float offset of the position's first-tap base in an A row
+    std::vector<int> pos_out;      // per position: float offset inside an output row
+    long long a_rowstride = 0, out_rowstride = 0;
+    int w_rowstride = 0, kch = 0, ncols = 0;
+    long long macs_per_row = 0;
+};
+// `p` must have been planned with bn == ncols (one PosEntry per position).
+BatchedPlan make_batched(const LayerPlan& p);
+
+// Job list of one launch: every class's M axis (n_rows * positions) cut into tiles, columns into tiles, ordered longest
+// first (the hardware dispatcher hands workgroups out in this order).  family 0: full tile 128x128, family 1: 128x64.
+// Built by simulating that dispatch (greedy list scheduling on `slots` equal servers, cost model below): jobs are taken
+// longest first, and one that would end later than `slack` x (total cost / slots) is cut in halves along M, then in
+// quarters along N (family 0 only) -- never along K -- whose pieces queue up again.  slack <= 0 picks, from a fixed ladder,
+// the value with the smallest simulated makespan; slack >= 1e20 never cuts.  min_level > 0 starts every tile cut to that
+// level (1 halves, 2 quarters): such a list needs less LDS and registers per workgroup, so the caller may pass more slots.
+struct JobModel {
+    // measured on MI355X at 12 500 rows (profiles/r02_*): TFLOP/s of a chip full of jobs of one shape, by (family, level),
+    // at the residency that shape allows (2 / 3 / 5 workgroups per CU), and the prologue + epilogue of one job in
+    // microseconds of its slot's time (from the K = 128 Linear layer, where they are a third of a job)
+    double rate[2][3] = {{141.5, 138.5, 134.0}, {136.5, 131.5, 131.5}};
+    double fixed_us[2][3] = {{7.5, 5.0, 3.4}, {5.0, 3.4, 3.4}};
+};
+std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, int slots, double slack,
+                                const JobModel& model = JobModel(), double* predicted_us = nullptr, int min_level = 0);
+// Makespan (microseconds) of greedy list scheduling of `jobs` in order on `slots` servers of 1/slots of the chip each.
+double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model);
+
 }  // namespace dg

@@ -61,4 +61,81 @@ void dgp_apply(void* h, const double* A, const double* W, const double* bias, do
             }
 }
 
+
+// ---- position-batched form: the job list of dg::build_jobs executed with host loops -------------------------------
+struct Batched {
+    dg::BatchedPlan plan;
+    std::vector<dg::JobDesc> jobs;
+    int family = 0;
+    double predicted_us = 0.0;
+};
+
+void* dgp2_build(void* layer_plan) {
+    Batched* b = new Batched();
+    b->plan = dg::make_batched(*static_cast<dg::LayerPlan*>(layer_plan));
+    b->family = b->plan.ncols % 128 == 0 ? 0 : 1;
+    return b;
+}
+void dgp2_free(void* h) { delete static_cast<Batched*>(h); }
+
+// info = n_classes, n_positions, n_taps, family
+void dgp2_info(void* h, long long* info) {
+    const Batched& b = *static_cast<Batched*>(h);
+    info[0] = (long long)b.plan.cls.size();
+    info[1] = (long long)b.plan.pos_a.size();
+    info[2] = (long long)b.plan.taps.size();
+    info[3] = b.family;
+}
+void dgp2_classes(void* h, int* out) {        // per class: pos_count, nchunks
+    const Batched& b = *static_cast<Batched*>(h);
+    for (size_t i = 0; i < b.plan.cls.size(); ++i) { out[2 * i] = b.plan.cls[i].pos_count; out[2 * i + 1] = b.plan.cls[i].nchunks; }
+}
+int dgp2_make_jobs(void* h, int n_rows, int slots, double alpha) {
+    Batched& b = *static_cast<Batched*>(h);
+    b.jobs = dg::build_jobs(b.plan, n_rows, b.family, slots, alpha, dg::JobModel(), &b.predicted_us);
+    return (int)b.jobs.size();
+}
+double dgp2_predicted_us(void* h) { return static_cast<Batched*>(h)->predicted_us; }
+void dgp2_jobs(void* h, int* out) {           // per job: cls, shape, n0, n_first, j_first, m_valid
+    const Batched& b = *static_cast<Batched*>(h);
+    for (size_t i = 0; i < b.jobs.size(); ++i) {
+        const dg::JobDesc& j = b.jobs[i];
+        int* o = out + 6 * i;
+        o[0] = j.cls; o[1] = j.shape; o[2] = j.n0; o[3] = j.n_first; o[4] = j.j_first; o[5] = j.m_valid;
+    }
+}
+// Executes the job list the way the device kernel addresses it (row split by the class's magic multiplier, a_off relative
+// to pos_a); `touched` (same shape as Out, int32) counts the writes per output element.
+void dgp2_apply(void* h, const double* A, const double* W, const double* bias, double* Out, int* touched, int mode) {
+    const Batched& b = *static_cast<Batched*>(h);
+    const dg::BatchedPlan& p = b.plan;
+    for (const dg::JobDesc& jb : b.jobs) {
+        const dg::ClassDesc& cd = p.cls[jb.cls];
+        const int bn = b.family == 0 ? (jb.shape == 2 ? 64 : 128) : 64;
+        const int n_taps = cd.nchunks / (p.kch / 32);
+        for (int r = 0; r < jb.m_valid; ++r) {
+            const unsigned jj = (unsigned)(jb.j_first + r);
+            const int q = cd.magic ? (int)(((unsigned long long)jj * cd.magic) >> 32) : (int)jj;
+            const int j = (int)jj - q * cd.pos_count;
+            const long long n = (long long)jb.n_first + q;
+            for (int c = 0; c < bn; ++c) {
+                const int col = jb.n0 + c;
+                double acc = 0.0;
+                for (int t = 0; t < n_taps; ++t) {
+                    const dg::TapEntry& te = p.taps[cd.tap_begin + t];
+                    const double* a = A + n * p.a_rowstride + p.pos_a[cd.pos_begin + j] + te.a_off;
+                    const double* w = W + te.w_off + (long long)col * p.w_rowstride;
+                    for (int k = 0; k < p.kch; ++k) acc += a[k] * w[k];
+                }
+                const long long o = n * p.out_rowstride + p.pos_out[cd.pos_begin + j] + col;
+                if (mode == 1 || mode == 2) acc += bias[col];
+                if (mode == 2) acc = acc > 0 ? acc : 0;
+                if (mode == 3) acc = Out[o] > 0 ? acc : 0;
+                Out[o] = acc;
+                touched[o] += 1;
+            }
+        }
+    }
+}
+
 }  // extern "C"

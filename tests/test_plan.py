@@ -28,6 +28,16 @@ def lib():
     l.dgp_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     l.dgp_tap_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp_apply.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int, C.c_int]
+    l.dgp2_build.restype = C.c_void_p
+    l.dgp2_build.argtypes = [C.c_void_p]
+    l.dgp2_free.argtypes = [C.c_void_p]
+    l.dgp2_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    l.dgp2_classes.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_make_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
+    l.dgp2_predicted_us.restype = C.c_double
+    l.dgp2_predicted_us.argtypes = [C.c_void_p]
+    l.dgp2_jobs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_apply.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
     return l
 
 
@@ -109,3 +119,116 @@ def test_linear_plans_vs_oracle(lib):
     apply(lib, h, da, W, None, part, N, 0)
     np.testing.assert_allclose(part.sum(axis=1), da @ W.T, rtol=1e-11, atol=1e-11)
     lib.dgp_free(h)
+
+
+# ---------------------------------------------------------------------------------- position-batched form (dg_gemm2.hip)
+def batched(lib, kind, *p):
+    h1, info = build(lib, kind, *p)
+    h2 = lib.dgp2_build(h1)
+    i2 = (C.c_longlong * 4)()
+    lib.dgp2_info(h2, i2)
+    cls = (C.c_int * (2 * i2[0]))()
+    lib.dgp2_classes(h2, cls)
+    return h1, h2, info, {"n_classes": i2[0], "n_pos": i2[1], "n_taps": i2[2], "family": i2[3],
+                          "classes": [(cls[2 * i], cls[2 * i + 1]) for i in range(i2[0])]}
+
+
+def jobs_of(lib, h2, n_rows, slots, alpha):
+    n = lib.dgp2_make_jobs(h2, n_rows, slots, alpha)
+    buf = (C.c_int * (6 * n))()
+    lib.dgp2_jobs(h2, buf)
+    return np.array(buf, np.int64).reshape(n, 6)
+
+
+def apply_jobs(lib, h2, A, W, bias, out, mode):
+    A = np.ascontiguousarray(A, np.float64); W = np.ascontiguousarray(W, np.float64)
+    b = np.ascontiguousarray(bias, np.float64) if bias is not None else np.zeros(1)
+    touched = np.zeros(out.shape, np.int32)
+    lib.dgp2_apply(h2, A.ctypes.data, W.ctypes.data, b.ctypes.data, out.ctypes.data, touched.ctypes.data, mode)
+    return touched
+
+
+def test_classes_of_the_mnist_layers(lib):
+    """Generator.2 forward (4x4 -> 7x7 used): per dimension the outputs fall in 4 relative-tap classes (1, 3, 1, 2 positions with
+    1, 2, 2, 3 taps) -> 16 classes; Generator.3 forward (7 -> 14): 5 per dimension -> 25; the stride-2 conv backward of
+    Generator.3 (7x7 grid reading 14x14): 3 per dimension -> 9, the interior class holds 25 positions x 25 taps."""
+    for kind, p, want_classes, biggest in [("deconv_fwd", (4, 4, 7, 7, 256, 128, 128), 16, (4, 9 * 8)),
+                                           ("deconv_fwd", (7, 7, 14, 14, 128, 64, 64), 25, (25, 9 * 4)),
+                                           ("deconv_bwd", (7, 7, 14, 14, 128, 64, 128), 9, (25, 25 * 2))]:
+        h1, h2, info, b = batched(lib, kind, *p)
+        assert b["n_classes"] == want_classes and b["classes"][0] == biggest
+        assert [c[1] for c in b["classes"]] == sorted([c[1] for c in b["classes"]], reverse=True)
+        assert sum(s * k for s, k in b["classes"]) * 32 * info["ncols"] == info["macs"]     # valid taps only, nothing added
+        lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+@pytest.mark.parametrize("kind,p,n_rows,alpha", [
+    ("deconv_fwd", (4, 4, 7, 7, 64, 128, 128), 37, 1e30),      # ragged M tiles, one job per tile
+    ("deconv_fwd", (4, 4, 7, 8, 64, 128, 128), 40, 0.05),      # everything cut to quarters, pitch > used extent
+    ("deconv_fwd", (7, 7, 14, 14, 32, 64, 64), 9, 0.0),        # 64-column family, cutting chosen by simulated makespan
+    ("deconv_bwd", (4, 4, 7, 7, 128, 64, 128), 50, 0.3),
+    ("deconv_bwd", (7, 7, 14, 14, 64, 32, 64), 21, 0.0),
+])
+def test_job_lists_cover_every_output_once_and_match_the_oracle(lib, kind, p, n_rows, alpha):
+    rs = np.random.RandomState(5)
+    h1, h2, info, b = batched(lib, kind, *p)
+    jobs = jobs_of(lib, h2, n_rows, 16, alpha)
+    assert len(jobs) > 0 and (jobs[:, 5] >= 1).all()
+    if kind == "deconv_fwd":
+        h_in, pitch_in, e, pitch_out, cin, cout, _ = p
+        x = rs.randn(n_rows, pitch_in, pitch_in, cin); F = rs.randn(5, 5, cout, cin); bias = rs.randn(cout)
+        out = np.full((n_rows, pitch_out, pitch_out, cout), 777.0)
+        touched = apply_jobs(lib, h2, x, F, bias, out, 2)
+        want = np.maximum(O.deconv2d(x[:, :h_in, :h_in], F, bias, e), 0)
+        np.testing.assert_allclose(out[:, :e, :e], want, rtol=1e-12, atol=1e-12)
+        assert (touched[:, :e, :e] == 1).all() and touched.sum() == n_rows * e * e * cout
+    else:
+        h_in, pitch_out, e, a_pitch, cin, cout, _ = p
+        dy = rs.randn(n_rows, a_pitch, a_pitch, cout); F = rs.randn(5, 5, cout, cin)
+        Ft = np.ascontiguousarray(F.transpose(0, 1, 3, 2))
+        hact = rs.randn(n_rows, pitch_out, pitch_out, cin)
+        out = hact.copy()
+        touched = apply_jobs(lib, h2, dy, Ft, None, out, 3)
+        want = O.deconv2d_backward_input(dy[:, :e, :e], F, h_in) * (hact[:, :h_in, :h_in] > 0)
+        np.testing.assert_allclose(out[:, :h_in, :h_in], want, rtol=1e-12, atol=1e-12)
+        assert (touched[:, :h_in, :h_in] == 1).all() and touched.sum() == n_rows * h_in * h_in * cin
+    lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_linear_layers_as_batched_jobs(lib):
+    rs = np.random.RandomState(6)
+    latent, feat, N = 64, 256, 70
+    z = rs.randn(N, latent); W = rs.randn(latent, feat); bvec = rs.randn(feat)
+    h1, h2, info, b = batched(lib, "linear_fwd", latent, feat, feat)
+    assert b["n_classes"] == 1 and b["family"] == 0
+    jobs_of(lib, h2, N, 8, 0.0)
+    out = np.zeros((N, feat))
+    assert (apply_jobs(lib, h2, z, np.ascontiguousarray(W.T), bvec, out, 1) == 1).all()
+    np.testing.assert_allclose(out, z @ W + bvec, rtol=1e-12, atol=1e-12)
+    lib.dgp2_free(h2); lib.dgp_free(h1)
+    da = rs.randn(N, feat)
+    nsplit = 4
+    h1, h2, info, b = batched(lib, "linear_bwd", latent, feat, nsplit, latent)
+    assert b["n_classes"] == nsplit and b["family"] == 1
+    jobs_of(lib, h2, N, 8, 0.0)
+    part = np.zeros((N, nsplit, latent))
+    assert (apply_jobs(lib, h2, da, W, None, part, 0) == 1).all()
+    np.testing.assert_allclose(part.sum(axis=1), da @ W.T, rtol=1e-11, atol=1e-11)
+    lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_job_cutting_levels_the_end_of_a_launch(lib):
+    """BASELINE configs[1] row count (2560): Generator.2 forward as 128x128 tiles alone leaves 980 jobs of very different
+    length for 512 slots; cutting the late jobs along M / N (never K) brings the simulated makespan within 8 % of the ideal."""
+    h1, h2, info, b = batched(lib, "deconv_fwd", 4, 4, 7, 7, 256, 128, 128)
+    plain = jobs_of(lib, h2, 2560, 512, 1e30)
+    t_plain = lib.dgp2_predicted_us(h2)
+    auto = jobs_of(lib, h2, 2560, 512, 0.0)
+    t_auto = lib.dgp2_predicted_us(h2)
+    assert len(plain) == 980 and (plain[:, 1] == 0).all() and len(auto) > len(plain)
+    ideal = 2.0 * info["macs"] * 2560 / 141.5e6               # microseconds at the full-tile rate of the cost model
+    assert t_auto < t_plain and t_auto < 1.08 * ideal + 8.0, (t_plain, t_auto, ideal)
+    order_cost = [b["classes"][c][1] * (128 if s == 0 else 64) * (64 if s == 2 else 128) for c, s in auto[:, :2]]
+    assert order_cost[:512] == sorted(order_cost[:512], reverse=True) and auto[0, 1] == 0      # whole long tiles first
+    assert set(auto[-64:, 1]) <= {1, 2}                                                        # small pieces last
+    lib.dgp2_free(h2); lib.dgp_free(h1)
