@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <queue>
@@ -79,7 +80,8 @@ struct GemmSchedule {
 // Job list of a position-batched launch (dg_gemm2.hip), one per row count a layer has been run with.
 struct JobList {
     int n_rows = 0, n_jobs = 0, min_level = 0;
-    double predicted_us = 0.0;
+    double predicted_us = 0.0;     // simulated makespan of the cost model
+    double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
     dg::JobDesc* d_jobs = nullptr;
 };
 
@@ -143,6 +145,7 @@ struct dg_handle {
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
     int job_slots_per_cu[2][3] = {{2, 3, 5}, {3, 5, 5}};   // resident workgroups per CU by (family, smallest level in the list)
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
+    int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
     dg::JobModel job_model;
     long long* d_job_trace = nullptr;
     std::string job_trace_op;
@@ -474,49 +477,13 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
-// Job list of `op` for this row count (built once, kept on the device).
-const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows) {
-    for (const auto& jl : op.jobs)
-        if (jl.n_rows == n_rows) return &jl;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    // A list that starts with full tiles leaves room for 2 (family 0) / 3 (family 1) workgroups per CU; lists cut to halves or
-    // quarters from the start need less LDS and registers (dg_gemm2.hip, MINLEVEL) and get more slots: the candidate with the
-    // smallest simulated makespan wins (small launches prefer many small jobs, large ones whole tiles).
-    JobList jl;
-    jl.n_rows = n_rows;
-    std::vector<dg::JobDesc> jobs;
-    const int n_levels = op.family == 0 ? 3 : 2;
-    for (int lvl = 0; lvl < n_levels; ++lvl) {
-        if (h->job_min_level >= 0 && lvl != h->job_min_level && !(h->job_min_level >= n_levels && lvl == n_levels - 1)) continue;
-        double t = 0.0;
-        std::vector<dg::JobDesc> cand = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl],
-                                                       h->job_slack, h->job_model, &t, lvl);
-        if (jobs.empty() || t < jl.predicted_us) { jobs.swap(cand); jl.predicted_us = t; jl.min_level = lvl; }
-    }
-    jl.n_jobs = (int)jobs.size();
-    if (hipMalloc(&jl.d_jobs, (jobs.size() + 1) * sizeof(dg::JobDesc)) != hipSuccess) return nullptr;
-    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(jl.d_jobs);
-        return nullptr;
-    }
-    if (op.jobs.size() >= 16) {                 // callers with many distinct batch sizes: keep the table bounded
-        (void)hipFree(op.jobs.front().d_jobs);
-        op.jobs.erase(op.jobs.begin());
-    }
-    op.jobs.push_back(jl);
-    return &op.jobs.back();
-}
-
-bool run_gemm2(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
-    const JobList* jl = get_jobs(h, op, n_rows);
-    if (!jl) return false;
+dg::Gemm2Args gemm2_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out) {
     dg::Gemm2Args a;
     a.A = A;
     a.W = op.W;
     a.Out = Out;
     a.bias = op.bias;
-    a.jobs = jl->d_jobs;
+    a.jobs = jl.d_jobs;
     a.cls = op.d_cls;
     a.taps = op.d_btaps;
     a.pos_a = op.d_pos_a;
@@ -526,11 +493,122 @@ bool run_gemm2(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows,
     a.w_rowstride = op.bplan.w_rowstride;
     a.kch = op.bplan.kch;
     a.mode = op.mode;
-    a.n_jobs = jl->n_jobs;
-    a.min_level = jl->min_level;
+    a.n_jobs = jl.n_jobs;
+    a.min_level = jl.min_level;
     a.trace = (h->d_job_trace && op.name == h->job_trace_op) ? h->d_job_trace : nullptr;
+    return a;
+}
+
+bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs) {
+    jl.n_jobs = (int)jobs.size();
+    if (hipMalloc(&jl.d_jobs, (jobs.size() + 1) * sizeof(dg::JobDesc)) != hipSuccess) return false;
+    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(jl.d_jobs);
+        jl.d_jobs = nullptr;
+        return false;
+    }
+    return true;
+}
+
+// Job list of `op` for this row count (built on first use, kept on the device).
+//
+// Candidates: a list that starts with full tiles leaves room for 2 (family 0) / 3 (family 1) workgroups per CU; lists cut
+// to halves or quarters from the start need less LDS and registers (dg_gemm2.hip, MINLEVEL) and get more slots; each with a
+// few cutting thresholds (dg_plan.h build_jobs).  Every candidate computes bit-identical results (cuts are along M / N
+// only), so the choice is purely one of speed: with `job_tune` the candidates are TIMED on the layer's real operands (the
+// launch is repeated on the actual input; an in-place ReluGrad layer writes to a scratch copy of its output) and the fastest
+// is kept; without it the cost model's simulated makespan decides.
+const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, float* Out, hipStream_t s) {
+    for (const auto& jl : op.jobs)
+        if (jl.n_rows == n_rows) return &jl;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    struct Cand { JobList jl; std::vector<dg::JobDesc> jobs; float ms = 0.f; };
+    std::vector<Cand> cands;
+    const int n_levels = op.family == 0 ? 3 : 2;
+    const bool tune = h->job_tune && h->job_slack <= 0.0 && A && Out;
+    const double slacks_tune[] = {1e30, 0.96, 1.0, 1.04, 1.1};
+    const double slack_one[] = {h->job_slack};
+    const double* slacks = tune ? slacks_tune : slack_one;
+    const int n_slacks = tune ? 5 : 1;
+    for (int lvl = 0; lvl < n_levels; ++lvl) {
+        if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
+        for (int k = 0; k < n_slacks; ++k) {
+            Cand c;
+            c.jl.n_rows = n_rows;
+            c.jl.min_level = lvl;
+            c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
+                                    h->job_model, &c.jl.predicted_us, lvl);
+            bool dup = false;
+            for (const Cand& o : cands)
+                dup = dup || (o.jl.min_level == lvl && o.jobs.size() == c.jobs.size() &&
+                              std::memcmp(o.jobs.data(), c.jobs.data(), c.jobs.size() * sizeof(dg::JobDesc)) == 0);
+            if (!dup) cands.push_back(std::move(c));
+        }
+    }
+    if (cands.empty()) return nullptr;
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); ++i)
+        if (cands[i].jl.predicted_us < cands[best].jl.predicted_us) best = i;
+    if (tune && cands.size() > 1) {
+        float* scratch = nullptr;
+        float* out = Out;
+        const size_t out_bytes = (size_t)n_rows * op.bplan.out_rowstride * sizeof(float);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+        if (ok && op.mode == dg::EPI_MASK) {          // in place over its gates: time it on a copy
+            ok = hipMalloc(&scratch, out_bytes) == hipSuccess &&
+                 hipMemcpyAsync(scratch, Out, out_bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
+            out = scratch;
+        }
+        for (size_t i = 0; ok && i < cands.size(); ++i) {
+            Cand& c = cands[i];
+            if (!upload_jobs(c.jl, c.jobs)) { ok = false; break; }
+            const dg::Gemm2Args a = gemm2_args(h, op, c.jl, A, out);
+            // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
+            // two events holds no host submission gaps; short layers are repeated more often.
+            const int reps = std::max(2, std::min(16, (int)(1500.0 / std::max(c.jl.predicted_us, 1.0))));
+            dg::launch_gemm2(op.family, a, s);
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < reps; ++rep) dg::launch_gemm2(op.family, a, s);
+            (void)hipEventRecord(e1, s);
+            float ms = 0.f;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { ok = false; break; }
+            c.ms = ms / reps;
+        }
+        if (ok) {
+            for (size_t i = 0; i < cands.size(); ++i)
+                if (cands[i].ms < cands[best].ms) best = i;
+            cands[best].jl.measured_us = cands[best].ms * 1e3;
+            if (getenv("DG_TUNE_VERBOSE")) {
+                for (size_t i = 0; i < cands.size(); ++i)
+                    fprintf(stderr, "[dg tune] %s rows %d level %d jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(), n_rows,
+                            cands[i].jl.min_level, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
+                            i == best ? "  <- kept" : "");
+            }
+        }
+        for (size_t i = 0; i < cands.size(); ++i)
+            if (i != best && cands[i].jl.d_jobs) { (void)hipFree(cands[i].jl.d_jobs); cands[i].jl.d_jobs = nullptr; }
+        if (scratch) (void)hipFree(scratch);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    JobList jl = cands[best].jl;
+    if (!jl.d_jobs && !upload_jobs(jl, cands[best].jobs)) return nullptr;
+    if (op.jobs.size() >= 16) {                 // callers with many distinct batch sizes: keep the table bounded
+        (void)hipFree(op.jobs.front().d_jobs);
+        op.jobs.erase(op.jobs.begin());
+    }
+    op.jobs.push_back(jl);
+    return &op.jobs.back();
+}
+
+bool run_gemm2(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    const JobList* jl = get_jobs(h, op, n_rows, A, Out, s);
+    if (!jl) return false;
+    const dg::Gemm2Args a = gemm2_args(h, op, *jl, A, Out);
     char sym[64];
-    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d>", op.family, op.mode);
+    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, std::min(jl->min_level, op.family == 0 ? 2 : 1));
     ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
     dg::launch_gemm2(op.family, a, s);
     return true;
@@ -1212,7 +1290,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
-        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level") {
+        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1220,6 +1298,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.slots0") h->job_slots_per_cu[0][0] = (int)v > 0 ? (int)v : 1;
         else if (k == "jobs.slots1") h->job_slots_per_cu[1][0] = (int)v > 0 ? (int)v : 1;
         else if (k == "jobs.min_level") h->job_min_level = (int)v;
+        else if (k == "jobs.tune") h->job_tune = v != 0.0;
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
         for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
