@@ -70,14 +70,7 @@ struct ActInfo {
     float* bstats = nullptr;  // [2, bn_C]
 };
 
-// Balanced tile lists of a persistent GEMM launch (one per (tile shape, M-tile count, grid) a layer has been run with).
-struct GemmSchedule {
-    int tile = 0, n_mtiles = 0, grid = 0;
-    unsigned* d_off = nullptr;     // [grid + 1]
-    unsigned* d_list = nullptr;    // [n_pos * n_mtiles]
-};
-
-// Job list of a position-batched launch (dg_gemm2.hip), one per row count a layer has been run with.
+// Job list of a position-batched launch (dg_gemm.hip), one per row count a layer has been run with.
 struct JobList {
     int n_rows = 0, n_jobs = 0, min_level = 0;
     double predicted_us = 0.0;     // simulated makespan of the cost model
@@ -87,11 +80,6 @@ struct JobList {
 
 struct GemmOp {
     std::string name;
-    dg::LayerPlan plan;
-    dg::PosEntry* d_pos = nullptr;
-    dg::TapEntry* d_taps = nullptr;
-    std::vector<GemmSchedule> sched;
-    // position-batched form
     dg::BatchedPlan bplan;
     int family = 0;
     dg::ClassDesc* d_cls = nullptr;
@@ -99,7 +87,6 @@ struct GemmOp {
     int* d_pos_a = nullptr;
     int* d_pos_out = nullptr;
     std::vector<JobList> jobs;
-    int tile = 0;
     int mode = 0;
     const float* W = nullptr;
     const float* bias = nullptr;
@@ -137,11 +124,6 @@ struct dg_handle {
     GemmOp F1, B1;
     std::vector<GemmOp> Fd, Bd;   // per non-final deconv
     int nsplit = 8;
-    int xcd_map = 0;   // measured slower than position-major order on MI355X (profiles/r01 notes)
-    int lds_pad = 0;
-    int persistent = 1;            // balanced persistent tile lists (dg_gemm.hip): 0 = never, 1 = where measured to pay, 2 = every layer
-    int persist_wgs = 0;           // resident workgroups per CU in persistent mode, 0 = by the tile's LDS footprint
-    int gemm2 = 1;                 // 1 = position-batched GEMM (dg_gemm2.hip), 0 = per-position kernel (dg_gemm.hip)
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
     int job_slots_per_cu[2][3] = {{2, 3, 5}, {3, 5, 5}};   // resident workgroups per CU by (family, smallest level in the list)
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
@@ -160,10 +142,6 @@ struct dg_handle {
     static constexpr int kMaxGroups = 4;
     hipStream_t side_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
-    int clk_probe = 0;
-    std::string clk_probe_op;
-    long long* d_clk = nullptr;
-    std::map<std::string, int> tile_override;
 
     // workspace
     int64_t cap_rows = 0;
@@ -228,59 +206,6 @@ void prof_collect(dg_handle* h) {
     h->pending.clear();
 }
 
-void free_schedules(GemmOp& op) {
-    for (auto& sc : op.sched) {
-        if (sc.d_off) (void)hipFree(sc.d_off);
-        if (sc.d_list) (void)hipFree(sc.d_list);
-    }
-    op.sched.clear();
-}
-
-// Longest-processing-time-first split of a layer's tiles over `grid` persistent workgroups.  A tile's cost is its
-// K-chunk count plus a fixed prologue/epilogue share; tiles are taken in the launch order of the one-workgroup-per-
-// tile mode (positions sorted by K descending, M tiles innermost) and each goes to the least loaded workgroup, so
-// every list is itself longest-first and the lists differ by at most one short tile.
-const GemmSchedule* get_schedule(GemmOp& op, int tile, int n_mtiles, int grid) {
-    for (const auto& sc : op.sched)
-        if (sc.tile == tile && sc.n_mtiles == n_mtiles && sc.grid == grid) return &sc;
-    const int n_pos = (int)op.plan.pos.size();
-    const size_t n_tiles = (size_t)n_pos * n_mtiles;
-    const int cpt = op.plan.kch / 32;
-    std::vector<unsigned> order(n_tiles);
-    for (size_t i = 0; i < n_tiles; ++i) order[i] = (unsigned)i;
-    auto cost = [&](unsigned t) { return (long long)op.plan.pos[t / n_mtiles].tap_count * cpt + 2; };
-    std::stable_sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return cost(a) > cost(b); });
-    typedef std::pair<long long, int> Load;              // (load, workgroup), smallest load on top
-    std::priority_queue<Load, std::vector<Load>, std::greater<Load>> heap;
-    for (int w = 0; w < grid; ++w) heap.push(Load(0, w));
-    std::vector<std::vector<unsigned>> lists(grid);
-    for (unsigned t : order) {
-        Load l = heap.top();
-        heap.pop();
-        lists[l.second].push_back(t);
-        heap.push(Load(l.first + cost(t), l.second));
-    }
-    std::vector<unsigned> off(grid + 1, 0), flat;
-    flat.reserve(n_tiles);
-    for (int w = 0; w < grid; ++w) {
-        off[w] = (unsigned)flat.size();
-        flat.insert(flat.end(), lists[w].begin(), lists[w].end());
-    }
-    off[grid] = (unsigned)flat.size();
-    GemmSchedule sc;
-    sc.tile = tile; sc.n_mtiles = n_mtiles; sc.grid = grid;
-    if (hipMalloc(&sc.d_off, off.size() * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMalloc(&sc.d_list, flat.size() * sizeof(unsigned)) != hipSuccess) { (void)hipFree(sc.d_off); return nullptr; }
-    if (hipMemcpy(sc.d_off, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(sc.d_list, flat.data(), flat.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(sc.d_off);
-        (void)hipFree(sc.d_list);
-        return nullptr;              // the caller falls back to one workgroup per tile
-    }
-    op.sched.push_back(sc);
-    return &op.sched.back();
-}
-
 void free_batched(GemmOp& op) {
     for (auto& jl : op.jobs)
         if (jl.d_jobs) (void)hipFree(jl.d_jobs);
@@ -309,29 +234,6 @@ int upload_batched(GemmOp& op, const dg::LayerPlan& base) {
     return DG_OK;
 }
 
-int upload_plan(GemmOp& op) {
-    free_schedules(op);
-    if (op.d_pos) { (void)hipFree(op.d_pos); op.d_pos = nullptr; }
-    if (op.d_taps) { (void)hipFree(op.d_taps); op.d_taps = nullptr; }
-    HIP_TRY(hipMalloc(&op.d_pos, op.plan.pos.size() * sizeof(dg::PosEntry)));
-    HIP_TRY(hipMalloc(&op.d_taps, op.plan.taps.size() * sizeof(dg::TapEntry)));
-    HIP_TRY(hipMemcpy(op.d_pos, op.plan.pos.data(), op.plan.pos.size() * sizeof(dg::PosEntry), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(op.d_taps, op.plan.taps.data(), op.plan.taps.size() * sizeof(dg::TapEntry), hipMemcpyHostToDevice));
-    return DG_OK;
-}
-
-// Tile ids: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64 (BM x BN).  Output positions have very different K (1..9 or
-// 4..25 taps) and B*R ~ 1280-2560 gives only 20-40 M tiles, so the choice trades the steady-state rate of bigger tiles
-// (128x128: 136 TF, 64x128 / 128x64: 131, 64x64: 127) against dispatch balance.  Measured per layer on MI355X (DESIGN.md
-// section 4.1): the smallest tile wins or ties on every layer of both architectures at these row counts (e.g. MNIST B3
-// 401 -> 367 us, B2 360 -> 336, CelebA F2 230 -> 211; MNIST F2 ties), also under the balanced persistent tile lists.
-// `tile.<op>` overrides it per layer.
-int default_tile(const std::string& name, int ncols) {
-    (void)name;
-    (void)ncols;
-    return 3;
-}
-
 // Fills h->ai (geometry of every activation buffer) from the architecture and use_bn.
 void describe_activations(dg_handle* h) {
     const int nd = (int)h->dec.size();
@@ -356,43 +258,24 @@ void describe_activations(dg_handle* h) {
 }
 
 int build_plans(dg_handle* h) {
-    auto tile_for = [&](const std::string& name, int ncols) {
-        auto it = h->tile_override.find(name);
-        int t = it != h->tile_override.end() ? it->second : default_tile(name, ncols);
-        if (ncols % dg::gemm_tile_bn(t) != 0) t = (t & 1) ? 3 : 2;   // fall back to 64 columns
-        return t;
-    };
     describe_activations(h);
     {
         GemmOp& op = h->F1;
         op.name = "F1";
-        op.tile = tile_for(op.name, h->lin_out);
-        op.plan = dg::plan_linear_fwd(h->latent, h->lin_out, dg::gemm_tile_bn(op.tile));
         op.mode = h->use_bn ? dg::EPI_BIAS : dg::EPI_BIAS_RELU;
-        int rc = upload_plan(op);
-        if (rc) return rc;
-        rc = upload_batched(op, dg::plan_linear_fwd(h->latent, h->lin_out, h->lin_out));
+        int rc = upload_batched(op, dg::plan_linear_fwd(h->latent, h->lin_out, h->lin_out));
         if (rc) return rc;
     }
     {
         GemmOp& op = h->B1;
         op.name = "B1";
-        op.tile = tile_for(op.name, h->latent);
-        op.plan = dg::plan_linear_bwd(h->latent, h->lin_out, h->nsplit, dg::gemm_tile_bn(op.tile));
         op.mode = dg::EPI_STORE;
-        int rc = upload_plan(op);
-        if (rc) return rc;
-        rc = upload_batched(op, dg::plan_linear_bwd(h->latent, h->lin_out, h->nsplit, h->latent));
+        int rc = upload_batched(op, dg::plan_linear_bwd(h->latent, h->lin_out, h->nsplit, h->latent));
         if (rc) return rc;
     }
     const int nd = (int)h->dec.size();
     for (auto* v : {&h->Fd, &h->Bd})
-        for (auto& o : *v) {
-            if (o.d_pos) (void)hipFree(o.d_pos);
-            if (o.d_taps) (void)hipFree(o.d_taps);
-            free_schedules(o);
-            free_batched(o);
-        }
+        for (auto& o : *v) free_batched(o);
     h->Fd.assign(nd - 1, GemmOp());
     h->Bd.assign(nd - 1, GemmOp());
     for (int d = 0; d + 1 < nd; ++d) {
@@ -402,32 +285,21 @@ int build_plans(dg_handle* h) {
         {
             GemmOp& op = h->Fd[d];
             op.name = std::string("F") + s.name[10];     // "Generator.N" -> "FN"
-            op.tile = tile_for(op.name, s.cout);
-            // with BN every stored position is computed (statistics need the cropped row/column too)
-            op.plan = dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin, s.cout,
-                                          dg::gemm_tile_bn(op.tile));
             op.mode = out.has_bn ? dg::EPI_BIAS : (s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS);
-            int rc = upload_plan(op);
-            if (rc) return rc;
-            rc = upload_batched(op, dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin,
-                                                        s.cout, s.cout));
+            // with BN every stored position is computed (statistics need the cropped row/column too)
+            int rc = upload_batched(op, dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch,
+                                                            s.cin, s.cout, s.cout));
             if (rc) return rc;
         }
         {
             GemmOp& op = h->Bd[d];
             op.name = std::string("B") + s.name[10];
-            op.tile = tile_for(op.name, s.cin);
-            // the incoming gradient is non-zero on the whole stored map after a BN backward, else only on the used block
-            op.plan = dg::plan_deconv_bwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin, s.cout,
-                                          dg::gemm_tile_bn(op.tile));
-            if (in.pitch > in.valid) dg::plan_add_zero_positions(op.plan, in.valid, in.pitch, s.cin);
             op.mode = dg::EPI_MASK;      // every backward output lands on a ReLU activation (h1, h2, h3)
-            int rc = upload_plan(op);
-            if (rc) return rc;
+            // the incoming gradient is non-zero on the whole stored map after a BN backward, else only on the used block
             dg::LayerPlan base = dg::plan_deconv_bwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin,
                                                      s.cout, s.cin);
             if (in.pitch > in.valid) dg::plan_add_zero_positions(base, in.valid, in.pitch, s.cin);
-            rc = upload_batched(op, base);
+            int rc = upload_batched(op, base);
             if (rc) return rc;
         }
     }
@@ -477,8 +349,8 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
-dg::Gemm2Args gemm2_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out) {
-    dg::Gemm2Args a;
+dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out) {
+    dg::GemmArgs a;
     a.A = A;
     a.W = op.W;
     a.Out = Out;
@@ -513,7 +385,7 @@ bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs) {
 // Job list of `op` for this row count (built on first use, kept on the device).
 //
 // Candidates: a list that starts with full tiles leaves room for 2 (family 0) / 3 (family 1) workgroups per CU; lists cut
-// to halves or quarters from the start need less LDS and registers (dg_gemm2.hip, MINLEVEL) and get more slots; each with a
+// to halves or quarters from the start need less LDS and registers (dg_gemm.hip, MINLEVEL) and get more slots; each with a
 // few cutting thresholds (dg_plan.h build_jobs).  Every candidate computes bit-identical results (cuts are along M / N
 // only), so the choice is purely one of speed: with `job_tune` the candidates are TIMED on the layer's real operands (the
 // launch is repeated on the actual input; an in-place ReluGrad layer writes to a scratch copy of its output) and the fastest
@@ -564,13 +436,13 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         for (size_t i = 0; ok && i < cands.size(); ++i) {
             Cand& c = cands[i];
             if (!upload_jobs(c.jl, c.jobs)) { ok = false; break; }
-            const dg::Gemm2Args a = gemm2_args(h, op, c.jl, A, out);
+            const dg::GemmArgs a = gemm_args(h, op, c.jl, A, out);
             // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
             // two events holds no host submission gaps; short layers are repeated more often.
             const int reps = std::max(2, std::min(16, (int)(1500.0 / std::max(c.jl.predicted_us, 1.0))));
-            dg::launch_gemm2(op.family, a, s);
+            dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e0, s);
-            for (int rep = 0; rep < reps; ++rep) dg::launch_gemm2(op.family, a, s);
+            for (int rep = 0; rep < reps; ++rep) dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e1, s);
             float ms = 0.f;
             if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { ok = false; break; }
@@ -603,66 +475,16 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     return &op.jobs.back();
 }
 
-bool run_gemm2(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+// One GEMM layer: the job list for this row count (built and, by default, chosen by timing on first use), one launch.
+int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
     const JobList* jl = get_jobs(h, op, n_rows, A, Out, s);
-    if (!jl) return false;
-    const dg::Gemm2Args a = gemm2_args(h, op, *jl, A, Out);
+    if (!jl) return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), n_rows);
+    const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out);
     char sym[64];
     snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, std::min(jl->min_level, op.family == 0 ? 2 : 1));
     ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
-    dg::launch_gemm2(op.family, a, s);
-    return true;
-}
-
-void run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
-    if (h->gemm2 && run_gemm2(h, op, A, Out, n_rows, s, prof)) return;
-    dg::GemmArgs a;
-    a.A = A;
-    a.W = op.W;
-    a.Out = Out;
-    a.bias = op.bias;
-    a.pos = op.d_pos;
-    a.taps = op.d_taps;
-    a.a_rowstride = op.plan.a_rowstride;
-    a.out_rowstride = op.plan.out_rowstride;
-    a.w_rowstride = op.plan.w_rowstride;
-    a.kch = op.plan.kch;
-    a.n_rows = n_rows;
-    // 128-row M tiles only pay off when there are enough of them to balance the dispatch (measured: CelebA F2 at
-    // N = 1280 rows runs 254 us with 128x128 tiles vs 240 us with 64x128); same BN, so the plan is unchanged.
-    int tile = op.tile;
-    if (dg::gemm_tile_bm(tile) == 128 && (long long)op.plan.pos.size() * ((n_rows + 127) / 128) < 4096) tile += 1;
-    const int bm = dg::gemm_tile_bm(tile);
-    a.n_mtiles = (n_rows + bm - 1) / bm;
-    a.mode = op.mode;
-    a.n_pos = (int)op.plan.pos.size();
-    a.xcd_map = h->xcd_map;
-    a.lds_pad = h->lds_pad;
-    a.clk = (h->clk_probe && op.name == h->clk_probe_op) ? h->d_clk : nullptr;
-    a.trace = nullptr;
-    a.sched_off = nullptr;
-    a.sched_list = nullptr;
-    a.sched_grid = 0;
-    // Measured on MI355X (probe_tiles, N = 2560 / 1280): the balanced persistent split pays where a layer has only
-    // ~1-2.5 long tiles per resident slot (backward of Generator.2: -5 % MNIST, -9 % CelebA) and costs 1-4 % on the
-    // layers with many short tiles, whose dispatch gaps are already covered by the other workgroups of the CU.
-    const bool want_persistent = h->persistent == 2 || (h->persistent == 1 && op.name == "B2");
-    if (want_persistent && !h->xcd_map) {
-        // resident workgroups per CU by the tile's LDS footprint (160 KB per CU): 64x64 -> 4, 48 KB tiles -> 3, 128x128 -> 2
-        const int lds_kb = 2 * (bm + dg::gemm_tile_bn(tile)) / 8;
-        int per_cu = h->persist_wgs > 0 ? h->persist_wgs : (lds_kb <= 32 ? 4 : lds_kb <= 48 ? 3 : 2);
-        const long long n_tiles = (long long)a.n_pos * a.n_mtiles;
-        const int grid = (int)std::min<long long>(n_tiles, 256LL * per_cu);
-        if (n_tiles > grid) {
-            const GemmSchedule* sc = get_schedule(op, tile, a.n_mtiles, grid);
-            if (sc) { a.sched_off = sc->d_off; a.sched_list = sc->d_list; a.sched_grid = sc->grid; }
-        }
-    }
-    // profile entries are "<layer>@<kernel symbol>" so that bench.py can group launches the way rocprofv3 does
-    char sym[64];
-    snprintf(sym, sizeof sym, "@gemm_gather_kernel<%d, %d, %d>", dg::gemm_tile_bm(tile), dg::gemm_tile_bn(tile), op.mode);
-    ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.plan.macs_per_row * n_rows);
-    dg::launch_gemm(tile, a, (int)op.plan.pos.size(), s);
+    dg::launch_gemm(op.family, a, s);
+    return DG_OK;
 }
 
 // A row group = a contiguous range of latent rows (whole images) processed on one stream.  Rows are independent
@@ -690,18 +512,20 @@ dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
 // forward chain at the current h->z; fills activations, loss, (y when want_y); when tail_backward the tail also
 // leaves the gradient w.r.t. the last GEMM activation in place.  x points at image 0 of the CALL (row0 / R
 // images are skipped inside).  With use_bn the whole call is one row group (batch statistics couple all rows).
-void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool tail_backward, bool prof) {
+int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool tail_backward, bool prof) {
     const int n_rows = g.n_rows;
     hipStream_t s = g.s;
     const int64_t r0 = g.row0;
-    run_gemm(h, h->F1, h->z + r0 * h->latent, h->act[0] + r0 * h->act_row[0], n_rows, s, prof);
+    int rc = run_gemm(h, h->F1, h->z + r0 * h->latent, h->act[0] + r0 * h->act_row[0], n_rows, s, prof);
+    if (rc) return rc;
     if (h->ai[0].has_bn) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
         dg::launch_bn_forward(bn_args(h, h->ai[0], n_rows), 1, s);
     }
     const int nd = (int)h->dec.size();
     for (int d = 0; d + 1 < nd; ++d) {
-        run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], h->act[d + 1] + r0 * h->act_row[d + 1], n_rows, s, prof);
+        rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], h->act[d + 1] + r0 * h->act_row[d + 1], n_rows, s, prof);
+        if (rc) return rc;
         if (h->ai[d + 1].has_bn) {
             ProfScope ps(h, s, prof, "BNf", 0.0);
             dg::launch_bn_forward(bn_args(h, h->ai[d + 1], n_rows), 1, s);
@@ -758,9 +582,10 @@ void run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wa
             dg::launch_celeba_tail_bwd_mfma(t, s);
         }
     }
+    return DG_OK;
 }
 
-void run_backward(dg_handle* h, const RowGroup& g, bool prof) {
+int run_backward(dg_handle* h, const RowGroup& g, bool prof) {
     const int nd = (int)h->dec.size();
     const int64_t r0 = g.row0;
     for (int d = nd - 2; d >= 0; --d) {
@@ -768,13 +593,14 @@ void run_backward(dg_handle* h, const RowGroup& g, bool prof) {
             ProfScope ps(h, g.s, prof, "BNb", 0.0);
             dg::launch_bn_backward(bn_args(h, h->ai[d + 1], g.n_rows), g.s);
         }
-        run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof);
+        int rc = run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof);
+        if (rc) return rc;
     }
     if (h->ai[0].has_bn) {
         ProfScope ps(h, g.s, prof, "BNb", 0.0);
         dg::launch_bn_backward(bn_args(h, h->ai[0], g.n_rows), g.s);
     }
-    run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
+    return run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
 
 // (Re)builds every layer plan and re-attaches the weight pointers (dg_create, tuning options).
@@ -912,7 +738,6 @@ int dg_destroy(dg_handle* h) {
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
     if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
     if (h->d_job_trace) (void)hipFree(h->d_job_trace);
-    if (h->d_clk) { (void)hipFree(h->d_clk); h->d_clk = nullptr; }
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
         if (h->side_stream[i]) { (void)hipStreamSynchronize(h->side_stream[i]); (void)hipStreamDestroy(h->side_stream[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -921,13 +746,7 @@ int dg_destroy(dg_handle* h) {
     for (auto& p : h->F) fr(p);
     for (auto& p : h->Ft) fr(p);
     for (auto& p : h->bias) fr(p);
-    auto frop = [](GemmOp& op) {
-        if (op.d_pos) (void)hipFree(op.d_pos);
-        if (op.d_taps) (void)hipFree(op.d_taps);
-        op.d_pos = nullptr; op.d_taps = nullptr;
-        free_schedules(op);
-        free_batched(op);
-    };
+    auto frop = [](GemmOp& op) { free_batched(op); };
     frop(h->F1); frop(h->B1);
     for (auto& o : h->Fd) frop(o);
     for (auto& o : h->Bd) frop(o);
@@ -1111,9 +930,11 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
         for (int gi = 0; gi < ngroups; ++gi) {
             const RowGroup& g = grp[gi];
-            run_forward(h, x, g, R, /*want_y=*/last, /*tail_backward=*/!last, prof);
+            rc = run_forward(h, x, g, R, /*want_y=*/last, /*tail_backward=*/!last, prof);
+            if (rc) return rc;
             if (last) continue;
-            run_backward(h, g, prof);
+            rc = run_backward(h, g, prof);
+            if (rc) return rc;
             ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
             const int64_t r0 = g.row0;
             dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
@@ -1145,7 +966,8 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)N * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     // the loss is discarded here: every row is compared with one all-zero image (R = N -> image 0)
     RowGroup g; g.n_rows = N; g.s = s;
-    run_forward(h, h->xzero, g, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, false);
+    rc = run_forward(h, h->xzero, g, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, false);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)N * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return DG_OK;
@@ -1165,11 +987,13 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     RowGroup g; g.n_rows = n_rows; g.s = s;
-    run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, false);
+    rc = run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, false);
+    if (rc) return rc;
     if (out_y) HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)n_rows * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_dz) {
-        run_backward(h, g, false);
+        rc = run_backward(h, g, false);
+        if (rc) return rc;
         dg::launch_momentum_update(nullptr, nullptr, h->part, h->nsplit, n_rows, h->latent, 0.f, 0.f, out_dz, s);
     }
     HIP_TRY(hipGetLastError());
@@ -1215,7 +1039,6 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
-    else if (w == "clk" && h->d_clk) { src = reinterpret_cast<const float*>(h->d_clk); avail = 4; }
     else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = 65536 * 4 * 2; }
     else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
@@ -1231,20 +1054,6 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
 int dg_set_option(dg_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
     const std::string k(key);
-    if (k.compare(0, 5, "tile.") == 0) {
-        const int t = atoi(value);
-        if (t < 0 || t > 3) return fail(DG_E_INVALID, "tile id must be 0..3");
-        h->tile_override[k.substr(5)] = t;
-        return rebuild_plans(h);
-    }
-    if (k == "clk_probe") {      // value = op name ("F3"); read back with dg_debug_read("clk")
-        HIP_TRY(hipSetDevice(h->device));
-        if (!h->d_clk) HIP_TRY(hipMalloc(&h->d_clk, 2 * sizeof(long long)));
-        HIP_TRY(hipMemset(h->d_clk, 0, 2 * sizeof(long long)));
-        h->clk_probe_op = value;
-        h->clk_probe = h->clk_probe_op.empty() ? 0 : 1;
-        return DG_OK;
-    }
     if (k == "two_streams") {
         h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..4)
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
@@ -1285,10 +1094,6 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->tail_dbg = atoi(value);
         return DG_OK;
     }
-    if (k == "gemm2") {
-        h->gemm2 = atoi(value) ? 1 : 0;
-        return DG_OK;
-    }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
         k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune") {
         HIP_TRY(hipSetDevice(h->device));
@@ -1311,22 +1116,6 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)65536 * 4 * sizeof(long long)));
         HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)65536 * 4 * sizeof(long long)));
         h->job_trace_op = value;
-        return DG_OK;
-    }
-    if (k == "persistent") {
-        h->persistent = atoi(value);
-        return DG_OK;
-    }
-    if (k == "persist_wgs") {
-        h->persist_wgs = atoi(value);
-        return DG_OK;
-    }
-    if (k == "lds_pad") {
-        h->lds_pad = atoi(value);
-        return DG_OK;
-    }
-    if (k == "xcd_map") {
-        h->xcd_map = atoi(value) ? 1 : 0;
         return DG_OK;
     }
     if (k == "nsplit") {

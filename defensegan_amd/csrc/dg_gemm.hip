@@ -1,17 +1,20 @@
-// Gathered implicit-GEMM kernel for gfx950 (MI355X): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// Position-batched gathered implicit GEMM for gfx950 (MI355X): exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
 //
-// Covers Linear fwd/bwd and every 5x5 stride-2 transposed conv fwd / backward-to-input of the
-// Defense-GAN generators (reference call sites: tflib/ops/linear.py:129-142,
-// tflib/ops/deconv2d.py:100-117).  M = latent rows (B*R), N = output channels of ONE output
-// position, K = (valid taps of that position) x (input channels): the tap list is resolved on the
-// host per position (dg_plan.cpp), so border taps are skipped exactly and zeros are never multiplied.
+// Every output element is one k-ordered fp32 fma chain over (tap, channel), taps in the planner's order (bit-identical to
+// the round-1 per-position kernel, profiles/r02_gemm2_bit_identity_vs_r01_kernel.txt).  Covers Linear fwd/bwd and every 5x5 stride-2 transposed conv fwd /
+// backward-to-input of the Defense-GAN generators (reference call sites: tflib/ops/linear.py:129-142,
+// tflib/ops/deconv2d.py:100-117).
 //
-// Data movement: both operands are K-contiguous in HBM (NHWC activations; filters [tap][n][k]), so a
-// 32-float K chunk of a row is one 128-B line.  Lines go HBM/L2 -> LDS with global_load_lds
-// (16 B/lane, no VGPR round trip), double buffered; the 16-B slot inside each LDS row is XOR-swizzled
-// through the per-lane SOURCE address so the ds_read_b128 fragment reads are bank-conflict free.
-// One b128 fragment read feeds four MFMAs: lane half h = lane>>5 holds k = 8*kk + 4*h + e for
-// e = 0..3, the same K permutation on A and B.
+// Structure:
+//  * M axis = (latent row, output position) pairs of one tap CLASS (dg_plan.cpp): positions with the same relative tap
+//    pattern share the filter slabs, so an M tile is dense for ANY batch size and every tile of a class has the same K.
+//  * One workgroup = one JOB from a host-built list ordered longest first; the hardware dispatcher is the (dynamic) queue.
+//    Jobs late in the list are the same tiles cut in halves / quarters along M and N (never along K, so every output
+//    element keeps its summation order whatever the batch looks like): big tiles for the MFMA rate, small ones to level
+//    the end of the launch.
+//  * 128x128 tiles (2x2 waves, 64x64 per wave, four independent accumulators): 8 operand lines staged per 64 MFMAs
+//    instead of 8 per 32; operand DMA through buffer_load ... lds with the chunk offset in an SGPR (no address VALU).
+//  * The fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk and pinned there.
 #include <type_traits>
 
 #include "dg_kernels.h"
@@ -21,85 +24,65 @@ namespace dg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define DG_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+int gemm_lds_bytes(int family, int min_level);
+
+namespace {
 
 constexpr int BK = 32;                 // floats per K chunk = one 128-B line per row
 constexpr int ROW_BYTES = BK * 4;
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
-    constexpr int TM = BM / 64;        // 32x32 sub-tiles per wave (waves are 2 x 2)
-    constexpr int TN = BN / 64;
-    constexpr int SA = BM / 32;        // staging slots (16 B each) per thread, A operand
-    constexpr int SB = BN / 32;
+// LLVM SchedGroupMask bits
+constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSREAD = 0x100;
+
+// (FAM, TAG only make every call site its own specialization: hipcc's host pass rejects a second reference to one)
+template <int TM, int TN, int MODE, int FAM, int TAG>
+__device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, char* smem) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;      // waves are 2 x 2, each owns TM x TN 32x32 accumulator tiles
+    constexpr int SA = BM / 32, SB = BN / 32;      // staging slots (one 1 KB wave-instruction each) per wave
+    constexpr int NS = SA + SB;
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    // measurement hook: shader-clock and 100 MHz real-time stamps of workgroup 0 (effective clock under load)
-    long long clk0 = 0, rt0 = 0;
-    if (g.clk && blockIdx.x == 0) { clk0 = clock64(); rt0 = wall_clock64(); }
     long long tr0 = 0;
     if (g.trace) tr0 = wall_clock64();
 
-    // Block -> (M tile, position) map.  xcd_map: workgroups are observed to land on XCD blockIdx % 8 (speed
-    // only, never correctness): XCD x walks M tiles x, x+8, ... and, for each, every output position
-    // (longest K first), so one M tile's input rows (1-3 MB) and the layer's filters stay in that XCD's 4 MB L2
-    // while all positions that re-read them are processed.
-    // Persistent mode (g.sched_off != nullptr): the grid is one resident set of workgroups, each walking its own
-    // host-built tile list (longest K first, balanced over the workgroups): a finished tile is followed by the next
-    // one without a trip through the hardware dispatcher (measured gap between two workgroups in one CU slot:
-    // median 5.7 us, profiles/r01_v3_timeline_F2_per_workgroup.csv).
-    unsigned sched_i = 0, sched_end = 0;
-    int tile_id = blockIdx.x;
-    if (g.sched_off) {
-        sched_i = g.sched_off[blockIdx.x];
-        sched_end = g.sched_off[blockIdx.x + 1];
-        if (sched_i >= sched_end) return;
-        tile_id = (int)g.sched_list[sched_i];
-    }
-  for (;;) {
-    int pn, mt;
-    if (g.xcd_map) {
-        const int xcd = tile_id & 7;
-        const int local = tile_id >> 3;
-        const int mg = local / g.n_pos;
-        pn = local - mg * g.n_pos;
-        mt = mg * 8 + xcd;
-        if (mt >= g.n_mtiles) return;
-    } else {
-        pn = tile_id / g.n_mtiles;
-        mt = tile_id - pn * g.n_mtiles;
-    }
-    const PosEntry pe = g.pos[pn];
-    const int pe_out_off = __builtin_amdgcn_readfirstlane(pe.out_off);
-    const int pe_n0 = __builtin_amdgcn_readfirstlane(pe.n0);
-    const int pe_tap_begin = __builtin_amdgcn_readfirstlane(pe.tap_begin);
-    const int pe_tap_count = __builtin_amdgcn_readfirstlane(pe.tap_count);
-    const int m0 = mt * BM;
+    const ClassDesc cd = g.cls[jb.cls];
+    const int s_cnt = cd.pos_count;
+    const unsigned magic = cd.magic;
+    const int m_valid = jb.m_valid;
+    // M row r of the job -> (latent row n_first + q, position j)
+    auto split = [&](int r, int& q, int& j) {
+        const unsigned jj = (unsigned)(jb.j_first + r);
+        q = magic ? (int)__umulhi(jj, magic) : (int)jj;
+        j = (int)jj - q * s_cnt;
+    };
 
-    // ---- per-thread staging sources (rows are fixed for the whole tile) -------------------------
-    const float* asrc[SA];
-    const float* wsrc[SB];
+    // ---- operand descriptors.  A: base = first latent row of the job; per-lane byte offset of its staging rows.
+    const float* a_base = g.A + (long long)jb.n_first * g.a_rowstride;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a_base), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, 0x7ffffff0, 0x00020000);
+    unsigned voff_a[SA], voff_w[SB];
 #pragma unroll
     for (int s = 0; s < SA; ++s) {
         const int r = (s * 4 + wave) * 8 + (lane >> 3);           // row inside the A tile
         const int c = (lane & 7) ^ swz(r);                         // source 16-B chunk for LDS slot lane&7
-        int n = m0 + r;
-        n = n < g.n_rows ? n : g.n_rows - 1;                       // ragged M: clamp loads, mask stores
-        asrc[s] = g.A + (long long)n * g.a_rowstride + c * 4;
+        const int rc = r < m_valid ? r : m_valid - 1;              // ragged M: clamp loads, mask stores
+        int q, j;
+        split(rc, q, j);
+        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + g.pos_a[cd.pos_begin + j]) * 4u + (unsigned)c * 16u;
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
         const int r = (s * 4 + wave) * 8 + (lane >> 3);           // output column inside the tile
         const int c = (lane & 7) ^ swz(r);
-        wsrc[s] = g.W + (long long)(pe_n0 + r) * g.w_rowstride + c * 4;
+        voff_w[s] = (unsigned)((jb.n0 + r) * g.w_rowstride) * 4u + (unsigned)c * 16u;
     }
 
     f32x16 acc[TM][TN];
@@ -111,40 +94,37 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int chunks_per_tap = g.kch / BK;
-    const int nchunks = pe_tap_count * chunks_per_tap;
-    const TapEntry* taps = g.taps + pe_tap_begin;
+    const int n_taps = cd.nchunks / chunks_per_tap;
+    const int nchunks = cd.nchunks;
+    const TapEntry* taps = g.taps + cd.tap_begin;
 
-    // Staging plan.  Slot s < SA stages 8 A rows per wave, slot s >= SA stages 8 filter rows; the slots of chunk
-    // c+1 are issued BETWEEN the MFMA groups of chunk c (slot s rides with k-step s % 4) instead of in one burst
-    // behind the barrier, where they would delay the first fragment reads of the chunk (measured: +12 % MFMA
-    // rate, tools/ubench/stage_cost4.hip).  The tap record of the NEXT tap is fetched one tap early (plain load).
-    constexpr int NS = SA + SB;
+    // Staging plan: the slots of chunk c+1 are issued BETWEEN the MFMA groups of chunk c (slot s rides with k-step s % 4).
     int ld_tap = 0, ld_k = 0;
-    TapEntry te_nxt = pe_tap_count > 0 ? taps[pe_tap_count > 1 ? 1 : 0] : TapEntry{0, 0};
-    const TapEntry te0 = pe_tap_count > 0 ? taps[0] : TapEntry{0, 0};
+    TapEntry te_nxt = n_taps > 0 ? taps[n_taps > 1 ? 1 : 0] : TapEntry{0, 0};
+    const TapEntry te0 = n_taps > 0 ? taps[0] : TapEntry{0, 0};
     int cur_a = __builtin_amdgcn_readfirstlane(te0.a_off);
     int cur_w = __builtin_amdgcn_readfirstlane(te0.w_off);
-    int aoff = 0, woff = 0;                    // operand offsets of the chunk being staged
+    int aoff = 0, woff = 0;                    // operand byte offsets of the chunk being staged (SGPRs)
     auto next_chunk_offsets = [&]() {
-        aoff = cur_a + ld_k;
-        woff = cur_w + ld_k;
+        aoff = (cur_a + ld_k) * 4;
+        woff = (cur_w + ld_k) * 4;
         ld_k += BK;
         if (ld_k == g.kch) {
             ld_k = 0;
             ++ld_tap;
             cur_a = __builtin_amdgcn_readfirstlane(te_nxt.a_off);
             cur_w = __builtin_amdgcn_readfirstlane(te_nxt.w_off);
-            const int nx = ld_tap + 1 < pe_tap_count ? ld_tap + 1 : pe_tap_count - 1;
+            const int nx = ld_tap + 1 < n_taps ? ld_tap + 1 : n_taps - 1;
             te_nxt = taps[nx];
         }
     };
     auto issue_slot = [&](int s, char* stage_base) {
         if (s < SA)
-            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(asrc[s < SA ? s : 0] + aoff),
-                                             DG_LDS_PTR(stage_base + (s * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, DG_LDS_PTR(stage_base + (s * 4 + wave) * 1024), 16,
+                                                     voff_a[s < SA ? s : 0], aoff, 0, 0);
         else
-            __builtin_amdgcn_global_load_lds(DG_GLOBAL_PTR(wsrc[s >= SA ? s - SA : 0] + woff),
-                                             DG_LDS_PTR(stage_base + BM * ROW_BYTES + ((s - SA) * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, DG_LDS_PTR(stage_base + BM * ROW_BYTES + ((s - SA) * 4 + wave) * 1024), 16,
+                                                     voff_w[s >= SA ? s - SA : 0], woff, 0, 0);
     };
 
     // fragment read addresses (byte offsets inside a stage), fixed per thread
@@ -164,27 +144,37 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         b_sw[j] = swz(r);
     }
 
-    // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk (instead of
-    // DMA for a next chunk), so their HBM/L2 latency hides under that chunk's MFMAs.
-    // Store layout of the epilogue (see below): pass p of tile (i, j) covers rows p*8 + (lane >> 3), columns 4*(lane & 7)..+3.
+    // Output rows of this lane in the epilogue: pass p of tile row-block i covers tile row wm*BM/2 + i*32 + p*8 + (lane >> 3),
+    // columns 4*(lane & 7)..+3 of each 32-column block.
     const int er = lane >> 3, ec = (lane & 7) * 4;
+    float* out_base = g.Out + (long long)jb.n_first * g.out_rowstride + jb.n0;
+    unsigned orow[TM][4];                          // float offset of the row inside the job's output window
+    bool ovalid[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = wm * (BM / 2) + i * 32 + p * 8 + er;
+            ovalid[i][p] = r < m_valid;
+            int q, j;
+            split(ovalid[i][p] ? r : 0, q, j);
+            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + g.pos_out[cd.pos_begin + j]);
+        }
+
+    // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk.
     f32x4 oldv[TM][TN][4];
     auto prefetch_mask = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = pe_n0 + wn * (BN / 2) + j * 32 + ec;
+            const int col = wn * (BN / 2) + j * 32 + ec;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row0 = m0 + wm * (BM / 2) + i * 32 + er;
-                const float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
-                const unsigned rs = (unsigned)g.out_rowstride;
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (row0 + p * 8 < g.n_rows) v = *reinterpret_cast<const f32x4*>(obase + (unsigned)(p * 8) * rs);
+                    if (ovalid[i][p]) v = *reinterpret_cast<const f32x4*>(out_base + orow[i][p] + col);
                     oldv[i][j][p] = v;
                 }
-            }
         }
     };
     if (MODE == EPI_MASK && nchunks == 0) {
@@ -195,14 +185,13 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) oldv[i][j][p] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (nchunks > 0) {                         // zero-tap positions (BN mode: cropped outputs) just store zeros
+    if (nchunks > 0) {
         next_chunk_offsets();
 #pragma unroll
         for (int s = 0; s < NS; ++s) issue_slot(s, smem);
     }
-    // One K chunk: wait for its operands, then 4 k-steps of MFMAs with the next chunk's DMA (or, in the LAST chunk of a
-    // ReluGrad tile, the mask prefetch) slotted between the MFMA groups.  The last chunk is peeled so the steady
-    // loop carries no "is there a next chunk" branches.
+    // One K chunk: wait for its operands, then 4 k-steps; the fragments of k-step kk+1 are read before the MFMAs of kk, and
+    // the next chunk's DMA (or, in the LAST chunk of a ReluGrad tile, the gate prefetch) rides between the MFMA groups.
     auto chunk_body = [&](int c, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -215,10 +204,11 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
         for (int i = 0; i < TM; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(st + a_rd[i] + ((fh ^ a_sw[i]) << 4));
 #pragma unroll
         for (int j = 0; j < TN; ++j) b[0][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((fh ^ b_sw[j]) << 4));
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk < 3) {                          // fragments of k-step kk+1 while kk computes
+        __builtin_amdgcn_sched_group_barrier(SG_DSREAD, TM + TN, 0);     // the k-step 0 fragments
+        auto kstep = [&](auto kk_tag) {
+            constexpr int kk = decltype(kk_tag)::value;
+            constexpr int cur = kk & 1, nxt = cur ^ 1;
+            if constexpr (kk < 3) {                // fragments of k-step kk+1 while kk computes
                 const int chunk = (kk + 1) * 2 + fh;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -227,59 +217,55 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     b[nxt][j] = *reinterpret_cast<const f32x4*>(st + b_rd[j] + ((chunk ^ b_sw[j]) << 4));
             }
+            constexpr int per_kk = (NS + 3) / 4;   // DMA slots riding with a k-step
+            constexpr int first = kk * per_kk;
+            constexpr int slots_here = LAST ? 0 : (first + per_kk <= NS ? per_kk : (NS > first ? NS - first : 0));
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
-            if constexpr (!LAST) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-                    if ((s & 3) == kk) issue_slot(s, nx);
-            } else if constexpr (MODE == EPI_MASK) {
-                if (kk == 0) prefetch_mask();
+                if constexpr (!LAST) {
+                    if (e < slots_here) issue_slot(first + e, nx);        // slot first+e rides behind MFMA group e
+                } else if constexpr (MODE == EPI_MASK) {
+                    if (kk == 0 && e == 0) prefetch_mask();
+                }
             }
-#pragma unroll
-            for (int e = 2; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
-        }
+            // pin the order: [fragment reads of kk+1] ([MFMA group] [DMA]) x slots_here [remaining MFMAs]
+            if constexpr (kk < 3) __builtin_amdgcn_sched_group_barrier(SG_DSREAD, TM + TN, 0);
+            if constexpr (slots_here >= 1) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            if constexpr (slots_here >= 2) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            if constexpr (slots_here >= 3) { __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN, 0); __builtin_amdgcn_sched_group_barrier(SG_VMEM, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(SG_MFMA, TM * TN * (4 - (slots_here > 3 ? 3 : slots_here)), 0);
+        };
+        kstep(std::integral_constant<int, 0>());
+        kstep(std::integral_constant<int, 1>());
+        kstep(std::integral_constant<int, 2>());
+        kstep(std::integral_constant<int, 3>());
     };
     for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::false_type());
     if (nchunks > 0) chunk_body(nchunks - 1, std::true_type());
 
-    if (g.clk && blockIdx.x == 0 && tid == 0) {
-        g.clk[0] = clock64() - clk0;
-        g.clk[1] = wall_clock64() - rt0;
-    }
     if (g.trace && tid == 0) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         long long* t = g.trace + (long long)blockIdx.x * 4;
         t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
     }
-    // ---- epilogue -------------------------------------------------------------------------------------------------
-    // D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each 32x32 accumulator tile is transposed through
-    // this wave's 4 KB slice of the stage buffer the last chunk did NOT use (nobody reads it any more: the barrier at the
-    // start of the last chunk retired its readers and the last chunk issues no DMA), so that a lane owns 4 consecutive
-    // channels of one row: 4 b128 stores (and, for ReluGrad, 4 b128 gate loads) per tile instead of 16 dword ones.
+    // ---- epilogue: each 32x32 accumulator tile is transposed through this wave's 4 KB slice of the stage the last chunk
+    // did NOT use, so that a lane owns 4 consecutive channels of one row: b128 stores (and b128 gate loads).
     float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = pe_n0 + wn * (BN / 2) + j * 32 + ec;
+        const int col = wn * (BN / 2) + j * 32 + ec;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + col);
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[i][j][e];
-            const int row0 = m0 + wm * (BM / 2) + i * 32 + er;
-            float* obase = g.Out + (long long)row0 * g.out_rowstride + pe_out_off + col;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
@@ -290,53 +276,74 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(GemmArgs g) {
                     if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
                     v[q] = t;
                 }
-                if (row0 + p * 8 < g.n_rows) *reinterpret_cast<f32x4*>(obase + (long long)(p * 8) * g.out_rowstride) = v;
+                if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
             }
         }
     }
-    if (!g.sched_off) return;
-    if (++sched_i >= sched_end) return;
-    tile_id = (int)g.sched_list[sched_i];
-    __syncthreads();                             // every wave is done with the LDS stages of this tile
-  }
 }
 
-template <int BM, int BN, int MODE>
-static void launch_tm(const GemmArgs& a, int n_pos, hipStream_t s) {
-    const int lds = 2 * (BM + BN) * ROW_BYTES + (a.lds_pad > 0 ? a.lds_pad : 0);   // 64x64: exactly 32 KB, five fit in 160 KB
+// FAM 0: layers with >= 128 output columns: job shapes 128x128 / 64x128 / 64x64.  FAM 1: 64-column layers: 128x64 / 64x64.
+// MINLEVEL = the smallest shape code in the launch's job list: a list without full tiles needs less LDS and fewer
+// registers, so more workgroups are resident per CU (launches too small to fill the chip with big tiles).
+template <int FAM, int MODE, int MINLEVEL>
+__global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (FAM == 0 && MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const JobDesc jb = g.jobs[blockIdx.x];
+    const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
+    if constexpr (FAM == 0) {
+        if constexpr (MINLEVEL <= 0) {
+            if (shape == 0) { run_job<2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        if constexpr (MINLEVEL <= 1) {
+            if (shape == 1) { run_job<1, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
+    } else {
+        if constexpr (MINLEVEL <= 0) {
+            if (shape == 0) { run_job<2, 1, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
+    }
+}
+
+template <int FAM, int MODE, int MINLEVEL>
+void launch_fml(const GemmArgs& a, hipStream_t s) {
+    const int lds = gemm_lds_bytes(FAM, MINLEVEL);
     static PerDeviceOnce attr;
-    if (attr.need(lds)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_gather_kernel<BM, BN, MODE>),
+    if (attr.need(lds))
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE, MINLEVEL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    }
-    unsigned grid = a.xcd_map ? 8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)n_pos
-                              : (unsigned)n_pos * (unsigned)a.n_mtiles;
-    if (a.sched_off) grid = (unsigned)a.sched_grid;
-    hipLaunchKernelGGL((gemm_gather_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
 }
 
-template <int BM, int BN>
-static void launch_t(const GemmArgs& a, int n_pos, hipStream_t s) {
+template <int FAM, int MODE>
+void launch_fm(const GemmArgs& a, hipStream_t s) {
+    if (a.min_level <= 0) launch_fml<FAM, MODE, 0>(a, s);
+    else if (FAM == 0 && a.min_level == 1) launch_fml<FAM, MODE, 1>(a, s);
+    else launch_fml<FAM, MODE, FAM == 0 ? 2 : 1>(a, s);
+}
+
+template <int FAM>
+void launch_f(const GemmArgs& a, hipStream_t s) {
     switch (a.mode) {
-        case EPI_STORE: launch_tm<BM, BN, EPI_STORE>(a, n_pos, s); break;
-        case EPI_BIAS: launch_tm<BM, BN, EPI_BIAS>(a, n_pos, s); break;
-        case EPI_BIAS_RELU: launch_tm<BM, BN, EPI_BIAS_RELU>(a, n_pos, s); break;
-        default: launch_tm<BM, BN, EPI_MASK>(a, n_pos, s); break;
+        case EPI_STORE: launch_fm<FAM, EPI_STORE>(a, s); break;
+        case EPI_BIAS: launch_fm<FAM, EPI_BIAS>(a, s); break;
+        case EPI_BIAS_RELU: launch_fm<FAM, EPI_BIAS_RELU>(a, s); break;
+        default: launch_fm<FAM, EPI_MASK>(a, s); break;
     }
 }
 
-static const int kTileBM[4] = {128, 64, 128, 64};
-static const int kTileBN[4] = {128, 128, 64, 64};
-int gemm_tile_bm(int tile) { return kTileBM[tile & 3]; }
-int gemm_tile_bn(int tile) { return kTileBN[tile & 3]; }
+}  // namespace
 
-void launch_gemm(int tile, const GemmArgs& a, int n_pos, hipStream_t s) {
-    switch (tile & 3) {
-        case 0: launch_t<128, 128>(a, n_pos, s); break;
-        case 1: launch_t<64, 128>(a, n_pos, s); break;
-        case 2: launch_t<128, 64>(a, n_pos, s); break;
-        default: launch_t<64, 64>(a, n_pos, s); break;
-    }
+// dynamic LDS of a launch: two stages of the largest job shape in its list
+int gemm_lds_bytes(int family, int min_level) {
+    const int rows = family == 0 ? (min_level <= 0 ? 256 : min_level == 1 ? 192 : 128) : (min_level <= 0 ? 192 : 128);
+    return 2 * rows * ROW_BYTES;
+}
+
+void launch_gemm(int family, const GemmArgs& a, hipStream_t s) {
+    if (a.n_jobs <= 0) return;
+    if (family == 0) launch_f<0>(a, s); else launch_f<1>(a, s);
 }
 
 }  // namespace dg

@@ -22,13 +22,6 @@ struct PerDeviceOnce {
 };
 
 
-// ---- gathered implicit GEMM -------------------------------------------------------------------
-// Out[n, pos, n0 + c] = epi( sum_{t in taps(pos)} sum_{k < kch} A[n*a_rowstride + a_off(t) + k]
-//                                                          * W[w_off(t) + (n0 + c)*w_rowstride + k] )
-// One workgroup = (M tile of BM latent rows) x (one output position) x (BN output columns).
-// Used for: Linear fwd/bwd (tflib/ops/linear.py:129-142), every Deconv2D fwd
-// (tf.nn.conv2d_transpose, tflib/ops/deconv2d.py:100-117) and its backward-to-input (a stride-2
-// SAME conv), with the 5x5 taps resolved per output position so that no zero is ever multiplied.
 enum EpiMode : int {
     EPI_STORE = 0,       // out = acc
     EPI_BIAS = 1,        // out = acc + bias[col]
@@ -36,43 +29,14 @@ enum EpiMode : int {
     EPI_MASK = 3,        // out = out_old > 0 ? acc : 0            (ReluGrad, in place over the activation)
 };
 
-struct GemmArgs {
-    const float* A;
-    const float* W;
-    float* Out;
-    const float* bias;
-    const PosEntry* pos;
-    const TapEntry* taps;
-    long long a_rowstride;
-    long long out_rowstride;
-    int w_rowstride;
-    int kch;             // K extent per tap, multiple of 32
-    int n_rows;
-    int n_mtiles;
-    int mode;
-    int n_pos;           // number of PosEntry records
-    int xcd_map;         // 1: XCD-aware block order (see dg_gemm.hip)
-    int lds_pad;         // extra dynamic LDS bytes (occupancy experiments)
-    long long* clk;      // optional [2]: shader-clock ticks, 100 MHz ticks spent by workgroup 0
-    // Persistent mode (sched_off != nullptr): the grid is one resident set of workgroups; workgroup w runs tiles
-    // sched_list[sched_off[w] .. sched_off[w+1]) (tile id = position * n_mtiles + m tile), a host-built
-    // longest-first balanced split (dg_engine.cpp, build_schedule).
-    const unsigned* sched_off;
-    const unsigned* sched_list;
-    int sched_grid;
-    long long* trace;    // optional [grid][4]: per-workgroup {start, end (100 MHz ticks), XCC id | CU id, chunks} (timeline probe)
-};
-
-// tile shapes: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64  (BM x BN)
-void launch_gemm(int tile, const GemmArgs& a, int n_pos, hipStream_t s);
-int gemm_tile_bm(int tile);
-int gemm_tile_bn(int tile);
-
-// ---- position-batched gathered implicit GEMM (dg_gemm2.hip) -------------------------------------
-// Same contraction, M axis = (latent row, output position) pairs of one tap class (dg_types.h), one workgroup per JobDesc.
+// ---- position-batched gathered implicit GEMM (dg_gemm.hip) --------------------------------------
+// Linear fwd/bwd (tflib/ops/linear.py:129-142), every Deconv2D fwd (tf.nn.conv2d_transpose, tflib/ops/deconv2d.py:100-117)
+// and its backward-to-input (a stride-2 SAME conv), with the 5x5 taps resolved per output position on the host so that no
+// zero is ever multiplied.  M axis = (latent row, output position) pairs of one tap class (dg_types.h), one workgroup per
+// JobDesc:
 //   Out[n, pos_out[j] + n0 + c] = epi( sum_{t in taps(class)} sum_{k < kch} A[n*a_rowstride + pos_a[j] + a_off(t) + k]
 //                                                                         * W[w_off(t) + (n0 + c)*w_rowstride + k] )
-struct Gemm2Args {
+struct GemmArgs {
     const float* A;
     const float* W;
     float* Out;
@@ -92,8 +56,8 @@ struct Gemm2Args {
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 };
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
-void launch_gemm2(int family, const Gemm2Args& a, hipStream_t s);
-int gemm2_lds_bytes(int family, int min_level);
+void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
+int gemm_lds_bytes(int family, int min_level);
 
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
 // dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.

@@ -38,7 +38,7 @@ LayerPlan plan_deconv_bwd(int h_in, int out_pitch, int e_out, int a_pitch, int c
 void plan_add_zero_positions(LayerPlan& p, int used, int pitch, int ncols);
 
 
-// ---- position-batched form (dg_gemm2.hip) -------------------------------------------------------
+// ---- position-batched form (dg_gemm.hip) -------------------------------------------------------
 // The same layer regrouped: output positions whose valid taps form the same RELATIVE pattern (same filter taps, same
 // input offsets relative to the position) are one class; the tap order inside a class is the per-position order above, so
 // every output element keeps its summation order.

@@ -128,17 +128,19 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
 
 /*
  * Tuning / measurement overrides (no reference counterpart; defaults are the measured optimum on MI355X):
- *   "tile.<op>"        GEMM tile of layer op (F1,F2,F3,F5,B5,B3,B2,B1): 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64
- *   "persistent"       balanced persistent tile lists: 0 never, 1 where measured to pay (default), 2 every layer
- *   "persist_wgs"      resident workgroups per CU in persistent mode (0 = by the tile's LDS footprint)
+ *   "jobs.tune"        1 (default): on first use of a row count every GEMM layer times its candidate job lists on the real
+ *                      operands and keeps the fastest; 0: the cost model's simulated makespan decides
+ *   "jobs.slack"       > 0 fixes the cutting threshold of the job lists (dg_plan.h build_jobs; 1e30 = whole tiles only)
+ *   "jobs.min_level"   >= 0 forces every list to start cut to halves (1) / quarters (2)
+ *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
  *   "nsplit"           split-K factor of the Linear backward (default 8)
  *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd16"       CelebA forward tail: 1 = 16x16x4 kh-aligned (default), 0 = 32x32x2
  *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel (0 = per-band kernel, "tail_bwd_bands")
- *   "tail_trace", "tail_dbg", "clk_probe", "xcd_map", "lds_pad"   measurement experiments (tools/)
- * Every launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py); "nsplit" and "tail_fwd16" change
- * a summation order (agreement to rounding).
+ *   "tail_trace", "tail_dbg", "job_trace"   measurement experiments (tools/)
+ * Every job-list / launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py): GEMM tiles are only
+ * ever cut along M and N, never along K; "nsplit" and "tail_fwd16" change a summation order (agreement to rounding).
  */
 int dg_set_option(dg_handle* h, const char* key, const char* value);
 

@@ -2,9 +2,9 @@
 
 * NET_DIM = 128 / LATENT_DIM = 64 (the C = 128 instantiations of every tail kernel, other K extents) against the
   float64 oracle;
-* launch-shape variants of the same arithmetic (tile shapes, balanced persistent tile lists, concurrent row groups,
-  non-persistent CelebA backward tail): each output element is the same fixed-order sum whatever the launch shape, so
-  these must reproduce the default engine BIT FOR BIT;
+* launch-shape variants of the same arithmetic (GEMM job lists: whole tiles only, everything cut to halves / quarters,
+  model-chosen instead of timed; concurrent row groups; non-persistent tails): each output element is the same fixed-order
+  sum whatever the launch shape, so these must reproduce the default engine BIT FOR BIT;
 * formulation variants whose summation order differs (CelebA 32-wide forward tail, split-K count): tolerance.
 """
 import numpy as np
@@ -69,17 +69,17 @@ def _run(gan, x, z0):
 
 
 BITWISE = {
-    "mnist": [{"tail_pipe": 0}, {"tail_pipe": 100}, {"persistent": 0}, {"persistent": 2}, {"two_streams": 2, "two_stream_min_rows": 64},
-              {"persistent": 2, "tile.F2": 0, "tile.B3": 0, "tile.B2": 0, "tile.F3": 2},
-              {"tile.F2": 1, "tile.B3": 1, "tile.B2": 2, "tile.F1": 1}],
-    "celeba": [{"persistent": 0}, {"persistent": 2, "tile.F2": 0, "tile.B3": 1}, {"tail_bwd_persist": 0},
-               {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300}],
+    "mnist": [{"tail_pipe": 0}, {"tail_pipe": 100}, {"two_streams": 2, "two_stream_min_rows": 64},
+              {"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01, "jobs.min_level": 0}, {"jobs.min_level": 1},
+              {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300}],
+    "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
+               {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300}],
 }
 
 
 @pytest.mark.parametrize("arch,B,R", [("mnist", 140, 10), ("celeba", 70, 10)])
 def test_launch_shape_variants_are_bit_identical(arch, B, R):
-    """1400 / 700 rows: more tiles than resident slots, so the persistent lists and both tail item loops iterate."""
+    """1400 / 700 rows: more jobs than resident slots in every list, and both tail item loops iterate."""
     a = archs.make_arch(arch)
     gan, p = _make(arch, R=R, L=3)
     rs = np.random.RandomState(7)

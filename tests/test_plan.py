@@ -121,7 +121,7 @@ def test_linear_plans_vs_oracle(lib):
     lib.dgp_free(h)
 
 
-# ---------------------------------------------------------------------------------- position-batched form (dg_gemm2.hip)
+# ---------------------------------------------------------------------------------- position-batched form (dg_gemm.hip)
 def batched(lib, kind, *p):
     h1, info = build(lib, kind, *p)
     h2 = lib.dgp2_build(h1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """GPU experiment helper: per-kernel timings of the projection loop under engine options.
 
-    python tools/probe_tiles.py --L 12 --set "tile.F2=0" --set "tile.F2=1,tile.B3=0" ...
+    python tools/probe_tiles.py --L 12 --set "jobs.tune=0" --set "jobs.slack=1e30,jobs.min_level=0" ...
 Each --set is one configuration (comma-separated key=value engine options); prints avg us / TFLOP/s per kernel.
 """
 import argparse
@@ -24,7 +24,6 @@ ap.add_argument("--L", type=int, default=12)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--set", action="append", default=[])
 ap.add_argument("--zero", action="store_true", help="all-zero weights (DVFS experiment)")
-ap.add_argument("--clk", default="", help="op name to clock-probe")
 args = ap.parse_args()
 
 a = archs.make_arch(args.arch)
@@ -55,15 +54,7 @@ for cfg in configs:
         gan.reconstruct(x, seed=2)
     ev1.record(); torch.cuda.synchronize()
     tot = ev0.elapsed_time(ev1) / args.reps
-    clk = None
-    if args.clk:
-        gan.set_option("clk_probe", args.clk)
-        for _ in range(2):
-            gan.reconstruct(x, seed=2)
-        torch.cuda.synchronize()
-        c = gan.debug_read("clk", 4).view(torch.int64).cpu().numpy()
-        clk = {"op": args.clk, "shader_ticks": int(c[0]), "rt_ticks_100MHz": int(c[1]), "GHz": round(c[0] / max(c[1], 1) * 0.1, 3)}
     line = {p["name"].split("@")[0]: (round(p["ms"] / p["launches"] * 1e3, 1), round(p["flops"] / p["ms"] / 1e9, 1)) for p in prof if p["launches"]}
     it_us = sum(v[0] for v in line.values())
-    print(json.dumps({"cfg": cfg, "per_iter_us": round(it_us, 1), "loop_ms_unprofiled": round(tot, 2), "kernels": line, "clk": clk}), flush=True)
+    print(json.dumps({"cfg": cfg, "per_iter_us": round(it_us, 1), "loop_ms_unprofiled": round(tot, 2), "kernels": line }), flush=True)
     gan.close()
