@@ -125,7 +125,7 @@ struct dg_handle {
     std::vector<GemmOp> Fd, Bd;   // per non-final deconv
     int nsplit = 8;
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
-    int job_slots_per_cu[2][3] = {{2, 3, 5}, {3, 5, 5}};   // resident workgroups per CU by (family, smallest level in the list)
+    int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};   // resident workgroups per CU by (family, smallest level in the list)
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
     dg::JobModel job_model;
@@ -397,7 +397,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     struct Cand { JobList jl; std::vector<dg::JobDesc> jobs; float ms = 0.f; };
     std::vector<Cand> cands;
-    const int n_levels = op.family == 0 ? 3 : 2;
+    const int n_levels = 3;
     const bool tune = h->job_tune && h->job_slack <= 0.0 && A && Out;
     const double slacks_tune[] = {1e30, 0.96, 1.0, 1.04, 1.1};
     const double slack_one[] = {h->job_slack};
@@ -481,7 +481,7 @@ int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, h
     if (!jl) return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), n_rows);
     const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out);
     char sym[64];
-    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, std::min(jl->min_level, op.family == 0 ? 2 : 1));
+    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, jl->min_level);
     ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
     dg::launch_gemm(op.family, a, s);
     return DG_OK;

@@ -12,7 +12,7 @@
 //    Jobs late in the list are the same tiles cut in halves / quarters along M and N (never along K, so every output
 //    element keeps its summation order whatever the batch looks like): big tiles for the MFMA rate, small ones to level
 //    the end of the launch.
-//  * 128x128 tiles (2x2 waves, 64x64 per wave, four independent accumulators): 8 operand lines staged per 64 MFMAs
+//  * 128x128 tiles (2x2 waves; 256x64 with 4x1 waves for the 64-column layers; 64x64 per wave, four independent accumulators): 8 operand lines staged per 64 MFMAs
 //    instead of 8 per 32; operand DMA through buffer_load ... lds with the chunk offset in an SGPR (no address VALU).
 //  * The fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk and pinned there.
 #include <type_traits>
@@ -39,9 +39,10 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSREAD = 0x100;
 
 // (FAM, TAG only make every call site its own specialization: hipcc's host pass rejects a second reference to one)
-template <int TM, int TN, int MODE, int FAM, int TAG>
+template <int TM, int TN, int WM, int WN, int MODE, int FAM, int TAG>
 __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, char* smem) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;      // waves are 2 x 2, each owns TM x TN 32x32 accumulator tiles
+    static_assert(WM * WN == 4, "four waves");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;   // waves are WM x WN, each owns TM x TN 32x32 accumulator tiles
     constexpr int SA = BM / 32, SB = BN / 32;      // staging slots (one 1 KB wave-instruction each) per wave
     constexpr int NS = SA + SB;
     constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
@@ -49,7 +50,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     long long tr0 = 0;
     if (g.trace) tr0 = wall_clock64();
 
@@ -133,18 +134,18 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     int a_rd[TM], b_rd[TN], a_sw[TM], b_sw[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int r = wm * (BM / 2) + i * 32 + frow;
+        const int r = wm * (BM / WM) + i * 32 + frow;
         a_rd[i] = r * ROW_BYTES;
         a_sw[i] = swz(r);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int r = wn * (BN / 2) + j * 32 + frow;
+        const int r = wn * (BN / WN) + j * 32 + frow;
         b_rd[j] = BM * ROW_BYTES + r * ROW_BYTES;
         b_sw[j] = swz(r);
     }
 
-    // Output rows of this lane in the epilogue: pass p of tile row-block i covers tile row wm*BM/2 + i*32 + p*8 + (lane >> 3),
+    // Output rows of this lane in the epilogue: pass p of tile row-block i covers tile row wm*BM/WM + i*32 + p*8 + (lane >> 3),
     // columns 4*(lane & 7)..+3 of each 32-column block.
     const int er = lane >> 3, ec = (lane & 7) * 4;
     float* out_base = g.Out + (long long)jb.n_first * g.out_rowstride + jb.n0;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int r = wm * (BM / 2) + i * 32 + p * 8 + er;
+            const int r = wm * (BM / WM) + i * 32 + p * 8 + er;
             ovalid[i][p] = r < m_valid;
             int q, j;
             split(ovalid[i][p] ? r : 0, q, j);
@@ -166,7 +167,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     auto prefetch_mask = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = wn * (BN / 2) + j * 32 + ec;
+            const int col = wn * (BN / WN) + j * 32 + ec;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -259,7 +260,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = wn * (BN / 2) + j * 32 + ec;
+        const int col = wn * (BN / WN) + j * 32 + ec;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
 #pragma unroll
@@ -282,27 +283,31 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     }
 }
 
-// FAM 0: layers with >= 128 output columns: job shapes 128x128 / 64x128 / 64x64.  FAM 1: 64-column layers: 128x64 / 64x64.
+// FAM 0: layers with >= 128 output columns: job shapes 128x128 / 64x128 / 64x64 (waves 2 x 2).
+// FAM 1: 64-column layers: 256x64 (waves 4 x 1: every wave reads the same 64 filter rows) / 128x64 / 64x64.
 // MINLEVEL = the smallest shape code in the launch's job list: a list without full tiles needs less LDS and fewer
 // registers, so more workgroups are resident per CU (launches too small to fill the chip with big tiles).
 template <int FAM, int MODE, int MINLEVEL>
-__global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (FAM == 0 && MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const JobDesc jb = g.jobs[blockIdx.x];
     const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
     if constexpr (FAM == 0) {
         if constexpr (MINLEVEL <= 0) {
-            if (shape == 0) { run_job<2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 0) { run_job<2, 2, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
         }
         if constexpr (MINLEVEL <= 1) {
-            if (shape == 1) { run_job<1, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 1) { run_job<1, 2, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
         }
-        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
+        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem);
     } else {
         if constexpr (MINLEVEL <= 0) {
-            if (shape == 0) { run_job<2, 1, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 0) { run_job<2, 2, 4, 1, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
         }
-        run_job<1, 1, MODE, FAM, MINLEVEL>(g, jb, smem);
+        if constexpr (MINLEVEL <= 1) {
+            if (shape == 1) { run_job<2, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+        }
+        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem);
     }
 }
 
@@ -319,8 +324,8 @@ void launch_fml(const GemmArgs& a, hipStream_t s) {
 template <int FAM, int MODE>
 void launch_fm(const GemmArgs& a, hipStream_t s) {
     if (a.min_level <= 0) launch_fml<FAM, MODE, 0>(a, s);
-    else if (FAM == 0 && a.min_level == 1) launch_fml<FAM, MODE, 1>(a, s);
-    else launch_fml<FAM, MODE, FAM == 0 ? 2 : 1>(a, s);
+    else if (a.min_level == 1) launch_fml<FAM, MODE, 1>(a, s);
+    else launch_fml<FAM, MODE, 2>(a, s);
 }
 
 template <int FAM>
@@ -337,7 +342,8 @@ void launch_f(const GemmArgs& a, hipStream_t s) {
 
 // dynamic LDS of a launch: two stages of the largest job shape in its list
 int gemm_lds_bytes(int family, int min_level) {
-    const int rows = family == 0 ? (min_level <= 0 ? 256 : min_level == 1 ? 192 : 128) : (min_level <= 0 ? 192 : 128);
+    const int rows = family == 0 ? (min_level <= 0 ? 256 : min_level == 1 ? 192 : 128)
+                                 : (min_level <= 0 ? 320 : min_level == 1 ? 192 : 128);     // BM + BN of the largest shape
     return 2 * rows * ROW_BYTES;
 }
 

@@ -173,15 +173,16 @@ BatchedPlan make_batched(const LayerPlan& p) {
 
 namespace {
 
-const int kFullBM[2] = {128, 128};
-const int kFullBN[2] = {128, 64};
+// job shapes (rows x columns) by (family, level); level + 1 is the same tile cut in two: along M, except family 0's last cut
+const int kShapeBM[2][3] = {{128, 64, 64}, {256, 128, 64}};
+const int kShapeBN[2][3] = {{128, 128, 64}, {64, 64, 64}};
 
-int shape_bm(int shape) { return shape == 0 ? 128 : 64; }
-int shape_bn(int family, int shape) { return family == 0 ? (shape == 2 ? 64 : 128) : 64; }
+int shape_bm(int family, int shape) { return kShapeBM[family][shape]; }
+int shape_bn(int family, int shape) { return kShapeBN[family][shape]; }
 
 double job_us(const BatchedPlan& p, const JobDesc& j, int family, int slots, const JobModel& m) {
     // a job occupies its tile's full MFMA footprint whatever m_valid is
-    const double flop = 2.0 * p.cls[j.cls].nchunks * 32.0 * shape_bm(j.shape) * shape_bn(family, j.shape);
+    const double flop = 2.0 * p.cls[j.cls].nchunks * 32.0 * shape_bm(family, j.shape) * shape_bn(family, j.shape);
     return flop / (m.rate[family][j.shape] * 1e6 / slots) + m.fixed_us[family][j.shape];
 }
 
@@ -190,9 +191,13 @@ double job_us(const BatchedPlan& p, const JobDesc& j, int family, int slots, con
 // the launch starts with whole tiles and ends with small ones.  The order of assignment is the dispatch order.
 std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int family, int slots, double slack, int min_level,
                                      const JobModel& model) {
-    const int BM = kFullBM[family], BN = kFullBN[family];
-    const int max_level = family == 0 ? 2 : 1;
+    const int BM = kShapeBM[family][0], BN = kShapeBN[family][0];
+    const int max_level = 2;
     if (min_level > max_level) min_level = max_level;
+    auto level_for_rows = [&](int rows, int level) {          // a ragged last tile starts at the level that still holds it
+        while (level < max_level && kShapeBM[family][level + 1] >= rows && kShapeBN[family][level + 1] == kShapeBN[family][level]) ++level;
+        return level;
+    };
     struct Piece { double us; int cls; int level; long long m0; int rows; int n0; unsigned seq; };
     auto cmp = [](const Piece& a, const Piece& b) { return a.us < b.us || (a.us == b.us && a.seq > b.seq); };
     std::priority_queue<Piece, std::vector<Piece>, decltype(cmp)> pool(cmp);
@@ -208,8 +213,8 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         for (long long m0 = 0; m0 < M; m0 += BM)
             for (int n0 = 0; n0 < p.ncols; n0 += BN) {
                 const int rows = (int)std::min<long long>(BM, M - m0);
-                const int level = std::max(min_level, rows <= BM / 2 ? 1 : 0);
-                const int bm = shape_bm(level), bn = shape_bn(family, level);
+                const int level = level_for_rows(rows, min_level);
+                const int bm = shape_bm(family, level), bn = shape_bn(family, level);
                 for (int r0 = 0; r0 < rows; r0 += bm)
                     for (int c0 = 0; c0 < BN; c0 += bn) {
                         Piece pc = {cost(c, level), c, level, m0 + r0, std::min(bm, rows - r0), n0 + c0, seq++};
@@ -227,19 +232,15 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         pool.pop();
         const double t0 = free_at.top();
         if (t0 + pc.us > target && pc.level < max_level) {
-            // cut: level 0 -> two halves along M; level 1 -> two quarters along N (family 0 only)
-            if (pc.level == 0) {
-                const int h = BM / 2;
-                for (int r0 = 0; r0 < pc.rows; r0 += h) {
-                    Piece q = {cost(pc.cls, 1), pc.cls, 1, pc.m0 + r0, std::min(h, pc.rows - r0), pc.n0, seq++};
+            // cut in two: along M while the next level is lower, else along N
+            const int nl = pc.level + 1;
+            const int bm = shape_bm(family, nl), bn = shape_bn(family, nl);
+            const int cols = shape_bn(family, pc.level);
+            for (int r0 = 0; r0 < pc.rows; r0 += bm)
+                for (int c0 = 0; c0 < cols; c0 += bn) {
+                    Piece q = {cost(pc.cls, nl), pc.cls, nl, pc.m0 + r0, std::min(bm, pc.rows - r0), pc.n0 + c0, seq++};
                     pool.push(q);
                 }
-            } else {
-                for (int c0 = 0; c0 < BN; c0 += 64) {
-                    Piece q = {cost(pc.cls, 2), pc.cls, 2, pc.m0, pc.rows, pc.n0 + c0, seq++};
-                    pool.push(q);
-                }
-            }
             continue;
         }
         free_at.pop();

@@ -56,18 +56,18 @@ struct BatchedPlan {
 BatchedPlan make_batched(const LayerPlan& p);
 
 // Job list of one launch: every class's M axis (n_rows * positions) cut into tiles, columns into tiles, ordered longest
-// first (the hardware dispatcher hands workgroups out in this order).  family 0: full tile 128x128, family 1: 128x64.
+// first (the hardware dispatcher hands workgroups out in this order).  family 0: full tile 128x128, family 1: 256x64.
 // Built by simulating that dispatch (greedy list scheduling on `slots` equal servers, cost model below): jobs are taken
-// longest first, and one that would end later than `slack` x (total cost / slots) is cut in halves along M, then in
-// quarters along N (family 0 only) -- never along K -- whose pieces queue up again.  slack <= 0 picks, from a fixed ladder,
+// longest first, and one that would end later than `slack` x (total cost / slots) is cut in two along M (family 0's second
+// cut: along N) -- never along K -- whose pieces queue up again, down to 64x64.  slack <= 0 picks, from a fixed ladder,
 // the value with the smallest simulated makespan; slack >= 1e20 never cuts.  min_level > 0 starts every tile cut to that
 // level (1 halves, 2 quarters): such a list needs less LDS and registers per workgroup, so the caller may pass more slots.
 struct JobModel {
     // measured on MI355X at 12 500 rows (profiles/r02_*): TFLOP/s of a chip full of jobs of one shape, by (family, level),
     // at the residency that shape allows (2 / 3 / 5 workgroups per CU), and the prologue + epilogue of one job in
     // microseconds of its slot's time (from the K = 128 Linear layer, where they are a third of a job)
-    double rate[2][3] = {{141.5, 138.5, 134.0}, {136.5, 131.5, 131.5}};
-    double fixed_us[2][3] = {{7.5, 5.0, 3.4}, {5.0, 3.4, 3.4}};
+    double rate[2][3] = {{141.5, 138.5, 134.0}, {139.0, 136.5, 131.5}};
+    double fixed_us[2][3] = {{7.5, 5.0, 3.4}, {7.5, 5.0, 3.4}};
 };
 std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, int slots, double slack,
                                 const JobModel& model = JobModel(), double* predicted_us = nullptr, int min_level = 0);

@@ -30,7 +30,7 @@ struct ClassDesc {
 };
 struct JobDesc {         // one workgroup = one job: (class, M range, column range, tile shape)
     int cls;
-    int shape;           // 0 = full tile, 1 = half (M halved), 2 = quarter (M and N halved); same arithmetic per element
+    int shape;           // cutting level: 0 = full tile (128x128 / 256x64), 1 = half, 2 = quarter (64x64); same arithmetic per element
     int n0;              // first output column
     int n_first;         // latent row of the job's first M row
     int j_first;         // position index (inside the class) of the job's first M row

@@ -111,7 +111,7 @@ void dgp2_apply(void* h, const double* A, const double* W, const double* bias, d
     const dg::BatchedPlan& p = b.plan;
     for (const dg::JobDesc& jb : b.jobs) {
         const dg::ClassDesc& cd = p.cls[jb.cls];
-        const int bn = b.family == 0 ? (jb.shape == 2 ? 64 : 128) : 64;
+        const int bn = b.family == 0 ? (jb.shape == 2 ? 64 : 128) : 64;      // columns of the job (dg_plan.cpp kShapeBN)
         const int n_taps = cd.nchunks / (p.kch / 32);
         for (int r = 0; r < jb.m_valid; ++r) {
             const unsigned jj = (unsigned)(jb.j_first + r);
