@@ -399,10 +399,10 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     std::vector<Cand> cands;
     const int n_levels = 3;
     const bool tune = h->job_tune && h->job_slack <= 0.0 && A && Out;
-    const double slacks_tune[] = {1e30, 0.96, 1.0, 1.04, 1.1};
+    const double slacks_tune[] = {1e30, 0.85, 0.92, 0.97, 1.0, 1.04, 1.1};
     const double slack_one[] = {h->job_slack};
     const double* slacks = tune ? slacks_tune : slack_one;
-    const int n_slacks = tune ? 5 : 1;
+    const int n_slacks = tune ? 7 : 1;
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
         for (int k = 0; k < n_slacks; ++k) {

@@ -9,14 +9,17 @@ import sys
 
 def summarize(path):
     c = sqlite3.connect(path)
+    # only the last projection call (after the second-to-last select_kernel): the first one also times candidate job lists
+    ids = sorted(set(d for d, in c.execute("select dispatch_id from counters_collection where kernel_name like '%select_kernel%'")))
+    first = ids[-2] if len(ids) >= 2 else -1
     cur = c.execute("select kernel_name, dispatch_id, counter_name, value, duration, grid_size, lds_block_size, "
-                    "vgpr_count, accum_vgpr_count, sgpr_count from counters_collection")
+                    "vgpr_count, accum_vgpr_count, sgpr_count from counters_collection where dispatch_id > ?", (first,))
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(set)
     dur = collections.defaultdict(dict)
     meta = {}
     for k, d, name, v, du, grid, lds, vg, ag, sg in cur:
-        k = k.split("(")[0][-48:]
+        k = k.replace("(anonymous namespace)::", "").split("(")[0][-48:]
         acc[k][name] += v
         cnt[k].add(d)
         dur[k][d] = du
