@@ -422,7 +422,8 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     size_t best = 0;
     for (size_t i = 1; i < cands.size(); ++i)
         if (cands[i].jl.predicted_us < cands[best].jl.predicted_us) best = i;
-    if (tune && cands.size() > 1) {
+    // launches of several milliseconds have thousands of jobs per slot wave: the lists differ by < 1 % there, not worth timing
+    if (tune && cands.size() > 1 && cands[best].jl.predicted_us < 3000.0) {
         float* scratch = nullptr;
         float* out = Out;
         const size_t out_bytes = (size_t)n_rows * op.bplan.out_rowstride * sizeof(float);
