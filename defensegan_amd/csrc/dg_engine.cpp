@@ -411,11 +411,27 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             c.jl.min_level = lvl;
             c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
                                     h->job_model, &c.jl.predicted_us, lvl);
-            bool dup = false;
-            for (const Cand& o : cands)
-                dup = dup || (o.jl.min_level == lvl && o.jobs.size() == c.jobs.size() &&
-                              std::memcmp(o.jobs.data(), c.jobs.data(), c.jobs.size() * sizeof(dg::JobDesc)) == 0);
-            if (!dup) cands.push_back(std::move(c));
+            auto add = [&](Cand&& x) {
+                for (const Cand& o : cands)
+                    if (o.jl.min_level == x.jl.min_level && o.jobs.size() == x.jobs.size() &&
+                        std::memcmp(o.jobs.data(), x.jobs.data(), x.jobs.size() * sizeof(dg::JobDesc)) == 0) return;
+                cands.push_back(std::move(x));
+            };
+            // A list that fits the resident slots is dispatched in one go, workgroup i to CU ~ i mod #CUs: with the jobs in
+            // descending order CU 0 collects the longest of every round and the last CU the shortest.  Second candidate:
+            // every other round of #CUs jobs reversed (boustrophedon), which evens the per-CU sums out (small batches).
+            const size_t slots = (size_t)cus * h->job_slots_per_cu[op.family][lvl];
+            if (tune && c.jobs.size() <= slots && c.jobs.size() > (size_t)cus) {
+                Cand sn;
+                sn.jl = c.jl;
+                sn.jobs = c.jobs;
+                for (size_t g0 = (size_t)cus; g0 < sn.jobs.size(); g0 += 2 * (size_t)cus)
+                    std::reverse(sn.jobs.begin() + g0, sn.jobs.begin() + std::min(sn.jobs.size(), g0 + (size_t)cus));
+                add(std::move(c));
+                add(std::move(sn));
+            } else {
+                add(std::move(c));
+            }
         }
     }
     if (cands.empty()) return nullptr;
