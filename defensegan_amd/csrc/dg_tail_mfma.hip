@@ -180,23 +180,39 @@ __device__ __forceinline__ void tail_bwd_tile_ldsw(const float* sg, int gbase, b
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
-    float gv[NS];
+    // The operand reads are issued in three batches, each waited for once: left to itself hipcc sinks every read to its use
+    // (ds_read; s_waitcnt lgkmcnt(0); mfma -- 2 * NS exposed LDS round trips per tile, 2/3 of this phase's time).  Bigger
+    // batches need more registers than the pipelined kernel (at its 168-VGPR cap) has: two batches already spill.
+    constexpr int BATCH = (NS + 2) / 3;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int k0 = 2 * s, k1 = 2 * s + 1;
-        const int t0 = k0 / COUT, c0 = k0 % COUT, t1 = (k1 < NK ? k1 : k0) / COUT, c1 = (k1 < NK ? k1 : k0) % COUT;
-        const int off0 = ((t0 / 5) * GWP + (t0 % 5)) * COUT + c0;
-        const int off1 = ((t1 / 5) * GWP + (t1 % 5)) * COUT + c1;
-        gv[s] = sg[gbase + (fh ? off1 : off0)];
-    }
+    for (int s0 = 0; s0 < NS; s0 += BATCH) {
+        float gv[BATCH];
+        float w[BATCH][U];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const float g = valid ? gv[s] : 0.f;
-        float w[U];
+        for (int q = 0; q < BATCH; ++q) {
+            const int s = s0 + q < NS ? s0 + q : NS - 1;
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int t0 = k0 / COUT, c0 = k0 % COUT, t1 = (k1 < NK ? k1 : k0) / COUT, c1 = (k1 < NK ? k1 : k0) % COUT;
+            const int off0 = ((t0 / 5) * GWP + (t0 % 5)) * COUT + c0;
+            const int off1 = ((t1 / 5) * GWP + (t1 % 5)) * COUT + c1;
+            gv[q] = sg[gbase + (fh ? off1 : off0)];
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = sWb[(s * 64 + lane) * U + u];
+            for (int u = 0; u < U; ++u) w[q][u] = sWb[(s * 64 + lane) * U + u];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(g, w[u], acc[u], 0, 0, 0);
+        for (int q = 0; q < BATCH; ++q) {
+            asm volatile("" : "+v"(gv[q]));
+#pragma unroll
+            for (int u = 0; u < U; ++u) asm volatile("" : "+v"(w[q][u]));
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            if (s0 + q >= NS) continue;
+            const float g = valid ? gv[q] : 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(g, w[q][u], acc[u], 0, 0, 0);
+        }
     }
 }
 
@@ -399,13 +415,36 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
     // lanes 32-63 for channel 8kk+4+e), and the backward epilogue needs one word per accumulator block instead of 16.
     auto fwd = [&](int k, const f32x4 (&av)[C / 8]) {
         unsigned* mk = smask + (k & 1) * MSZ + tile * C;
+        // word 8*kk + 4*half + e of the tile's C words = one half of a ballot; each is dropped into the lane that will store
+        // it (v_writelane), then ONE ds_write_b32 per 64 words (a per-ballot "if (lane < 2) store" costs a divergent
+        // branch and a store instruction for each of the C/2 ballots).  A VALU-written SGPR (v_cmp) is NOT safe as the data
+        // operand of a v_writelane issued right behind it on gfx950 (wrong masks without wait states; measured): the four
+        // ballots of a k-step are formed first, then 4 wait states, then their eight writes.
+        static_assert(C % 64 == 0, "C words per tile in groups of 64");
 #pragma unroll
-        for (int kk = 0; kk < C / 8; ++kk)
+        for (int w0 = 0; w0 < C; w0 += 64) {
+            int word = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned long long bal = __ballot(av[kk][e] > 0.f);
-                if (lane < 2) mk[8 * kk + 4 * lane + e] = lane ? (unsigned)(bal >> 32) : (unsigned)bal;
+            for (int kk = w0 / 8; kk < w0 / 8 + 8; ++kk) {
+                unsigned lo[4], hi[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned long long bal = __ballot(av[kk][e] > 0.f);
+                    lo[e] = __builtin_amdgcn_readfirstlane((unsigned)bal);
+                    hi[e] = __builtin_amdgcn_readfirstlane((unsigned)(bal >> 32));
+                }
+                asm volatile("s_nop 3\n\t"
+                             "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"
+                             "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                             "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"
+                             "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                             : "+v"(word)
+                             : "s"(lo[0]), "s"(lo[1]), "s"(lo[2]), "s"(lo[3]), "s"(hi[0]), "s"(hi[1]), "s"(hi[2]), "s"(hi[3]),
+                               "i"(8 * kk - w0), "i"(8 * kk + 1 - w0), "i"(8 * kk + 2 - w0), "i"(8 * kk + 3 - w0),
+                               "i"(8 * kk + 4 - w0), "i"(8 * kk + 5 - w0), "i"(8 * kk + 6 - w0), "i"(8 * kk + 7 - w0));
             }
+            mk[w0 + lane] = (unsigned)word;
+        }
         tail_fwd_compute_ldsw<C>(av, tile * 32, sWf, sP + (k & 1) * PSZ, MN_NKP, lane);
     };
     auto bwd = [&](int k) {
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
     const float bias = a.b5[0];
     const float gscale = 2.0f / 784.0f;
     auto load_x = [&](int k, float (&xv)[4]) {
-        const float* xrow = a.x + (row_of(k) / a.R) * 784;
+        const float* xrow = a.x + (long long)((unsigned)row_of(k) / (unsigned)a.R) * 784;     // rows < 2^24: 32-bit division
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int p = gt + 256 * r;
@@ -451,26 +490,42 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
         float* pg = sg + (k & 1) * GSZ;
         const long long n = row_of(k);
         float sq = 0.f;
+        // all 9 candidate taps of this thread's (up to) 4 pixels are read first and waited for once (hipcc otherwise reads,
+        // waits and sums pixel by pixel: 4 exposed LDS round trips under the M waves' LDS traffic); a missing tap reads the
+        // zero pad column 31.  The sums keep their order.
+        float tv[4][9];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int p = gt + 256 * r;
-            if (p >= 784) break;
             const int i = p / 28, j = p - i * 28;
             const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
-            float sacc = 0.f;
 #pragma unroll
             for (int ah = 0; ah < 3; ++ah) {
                 const int kh = kh0 + 2 * ah;
                 const int oh = (i + 1 - kh) >> 1;
-                const bool okh = !(kh > 4 || oh < 0 || oh >= 14);
+                const bool okh = p < 784 && !(kh > 4 || oh < 0 || oh >= 14);
 #pragma unroll
                 for (int aw = 0; aw < 3; ++aw) {
                     const int kw = kw0 + 2 * aw;
                     const int ow = (j + 1 - kw) >> 1;
                     const bool ok = okh && !(kw > 4 || ow < 0 || ow >= 14);
-                    sacc += pP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
+                    tv[r][ah * 3 + aw] = pP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
                 }
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(tv[r][t]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            if (p >= 784) break;
+            const int i = p / 28, j = p - i * 28;
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sacc += tv[r][t];
             const float y = 1.0f / (1.0f + expf(-(sacc + bias)));
             const float d = y - xv[r];
             sq = __builtin_fmaf(d, d, sq);
