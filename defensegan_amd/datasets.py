@@ -55,3 +55,99 @@ def to_generator_range(images: np.ndarray, dataset_name: str) -> np.ndarray:
     if dataset_name.lower() == "celeba":
         x = np.float32(2.0) * (x - np.float32(0.5))
     return x
+
+
+# ---------------------------------------------------------------------------------------------------- CelebA (64 x 64 x 3)
+# Counterpart of ``CelebA.load`` + ``LazyDataset`` (/root/reference/datasets/celeba.py:47-140, datasets/dataset.py:66-182,
+# 216-262): files ``{i:06d}.jpg`` (1-based), train / val / test = images 1-162770 / 162771-182637 / 182638-202599, each
+# image read on access, centre-cropped to 108 x 108 (top-left = round((h - 108) / 2), round((w - 108) / 2)) and resized to
+# 64 x 64 by ``scipy.misc.imresize`` -- which is PIL: the float crop is first byte-scaled over its OWN min / max
+# (scipy.misc.bytescale: (x - min) * 255 / (max - min) + 0.5 -> uint8), then ``Image.resize((64, 64), BILINEAR)``.  scipy.misc
+# no longer exists; its published semantics are restated here on top of Pillow (needed only for this loader).
+CELEBA_SPLITS = {"train": (1, 162770), "val": (162771, 182637), "dev": (162771, 182637), "test": (182638, 202599)}
+
+
+def _bytescale(data: np.ndarray) -> np.ndarray:
+    """scipy.misc.bytescale with its defaults (cmin / cmax = data min / max, low 0, high 255)."""
+    if data.dtype == np.uint8:
+        return data
+    cmin, cmax = float(data.min()), float(data.max())
+    cscale = cmax - cmin
+    if cscale == 0:
+        cscale = 1.0
+    scaled = (data.astype(np.float64) - cmin) * (255.0 / cscale)
+    return (scaled.clip(0, 255) + 0.5).astype(np.uint8)
+
+
+def prepare_celeba_image(image: np.ndarray, crop: int = 108, size: int = 64) -> np.ndarray:
+    """``_prepare_image(image, crop, crop, size, size, is_crop=True)`` (dataset.py:216-262): float [h,w,3] in [0,255] ->
+    uint8-valued float32 [size,size,3] in [0,255]."""
+    from PIL import Image           # only this loader needs Pillow
+    h, w = image.shape[:2]
+    j = int(np.floor((h - crop) / 2.0 + 0.5))     # Python-2 round(): half away from zero (non-negative here)
+    i = int(np.floor((w - crop) / 2.0 + 0.5))
+    patch = _bytescale(np.asarray(image[j:j + crop, i:i + crop], dtype=np.float64))
+    out = Image.fromarray(patch).resize((size, size), resample=Image.BILINEAR)
+    return np.asarray(out, dtype=np.float32)
+
+
+class LazyCelebA(object):
+    """``LazyDataset`` (dataset.py:66-182): indexable by int / slice / index array, loads on access."""
+
+    def __init__(self, filepaths, center_crop_dim: int = 108, resize_size: int = 64):
+        self.filepaths = list(filepaths)
+        self.center_crop_dim = center_crop_dim
+        self.resize_size = resize_size
+
+    def _get_image(self, path: str) -> np.ndarray:
+        from PIL import Image
+        with Image.open(path) as im:
+            arr = np.asarray(im.convert("RGB"), dtype=np.float64)
+        return prepare_celeba_image(arr, self.center_crop_dim, self.resize_size)
+
+    def __len__(self):
+        return len(self.filepaths)
+
+    def __getitem__(self, index):
+        if isinstance(index, (int, np.integer)):
+            return self._get_image(self.filepaths[int(index)])
+        if isinstance(index, slice):
+            index = range(*index.indices(len(self.filepaths)))
+        try:
+            inds = [int(i) for i in index]
+        except TypeError:
+            raise TypeError("Index must be an integer, a slice, a container or an integer generator.")
+        return np.array([self._get_image(self.filepaths[i]) for i in inds])
+
+    def get_subset(self, indices):
+        if isinstance(indices, slice):
+            indices = range(*indices.indices(len(self.filepaths)))
+        self.filepaths = [self.filepaths[int(i)] for i in indices]
+
+    @property
+    def shape(self):
+        return (None, self.resize_size, self.resize_size, 3)
+
+
+def load_celeba_split(data_dir: str, split: str = "test", attribute=None, randomize: bool = False, seed: int = 0):
+    """(lazy images, labels or None).  ``attribute='gender'`` reads the ``male`` column of ``list_attr_celeba.txt`` as 0 / 1
+    (celeba.py:113-131); file existence is not checked here (the reference does not either)."""
+    if split not in CELEBA_SPLITS:
+        raise ValueError("[!] Invalid split {}.".format(split))
+    start, end = CELEBA_SPLITS[split]
+    fps = [os.path.join(data_dir, "{:06d}.jpg".format(i)) for i in range(start, end + 1)]
+    labels = None
+    if attribute is not None:
+        if attribute != "gender":
+            raise ValueError("[!] Invalid attribute {} for CelebA dataset.".format(attribute))
+        with open(os.path.join(data_dir, "list_attr_celeba.txt")) as f:
+            lines = f.readlines()
+        names = [s.lower().replace(" ", "_") for s in lines[1].strip().split()]
+        col = names.index("male")
+        attrs = np.asarray([[int(v) for v in ln.split()[1:]] for ln in (l.strip() for l in lines[2:]) if ln], dtype=np.int64)
+        labels = ((attrs + 1) // 2)[start - 1:end, col].reshape(-1)
+    if randomize:
+        perm = np.random.RandomState(seed).permutation(len(fps))
+        fps = [fps[k] for k in perm]
+        labels = labels[perm] if labels is not None else None
+    return LazyCelebA(fps), labels

@@ -234,3 +234,44 @@ def test_command_line_surface():
     assert cfg["DATASET_NAME"] == "celeba" and cfg["IMAGE_DIM"] == [64, 64, 3]
     assert cfgmod.resolve_rec_params(cfg, a) == {"rec_rr": 4, "rec_lr": 10.0, "rec_iters": 50, "batch_size": 50}
     assert a.same_init and not a.raw and a.seed == 11241990
+
+
+def test_celeba_lazy_loader_crop_bytescale_resize(tmp_path):
+    """datasets/celeba.py + LazyDataset: 1-based {i:06d}.jpg files, split index ranges, centre crop 108 -> scipy.misc.imresize
+    (byte-scale over the crop's own min / max, PIL bilinear) -> 64x64x3, 'male' column as the label."""
+    PIL = pytest.importorskip("PIL.Image")
+    from defensegan_amd import datasets
+    assert datasets.CELEBA_SPLITS["train"] == (1, 162770) and datasets.CELEBA_SPLITS["test"] == (182638, 202599)
+    rs = np.random.RandomState(0)
+    # a smooth 218 x 178 image (CelebA's size) whose crop does NOT span 0..255: the byte-scaling must stretch it
+    yy, xx = np.mgrid[0:218, 0:178]
+    img = np.stack([60 + 0.5 * yy, 80 + 0.4 * xx, 100 + 0.2 * (xx + yy)], axis=-1).astype(np.float64)
+    got = datasets.prepare_celeba_image(img)
+    assert got.shape == (64, 64, 3) and got.dtype == np.float32 and got.min() >= 0 and got.max() <= 255
+    crop = img[55:163, 35:143]                                            # round((218-108)/2) = 55, round((178-108)/2) = 35
+    assert got.max() > 250 and got.min() < 5                               # stretched over the crop's own range
+    scaled = (crop - crop.min()) * 255.0 / (crop.max() - crop.min())
+    # bilinear 108 -> 64 with PIL's area-scaled triangle filter stays within a pixel value of simple block means of a ramp
+    centers = (np.arange(64) + 0.5) * 108 / 64 - 0.5
+    ref = np.stack([np.stack([scaled[int(round(cy)), int(round(cx))] for cx in centers]) for cy in centers])
+    assert np.abs(got - ref).max() <= 3.0
+    # file access: three tiny "dataset" images + attribute file, 1-based names
+    d = tmp_path / "celebA"
+    d.mkdir()
+    for i in (182638, 182639, 182640):
+        arr = rs.randint(0, 256, size=(218, 178, 3)).astype(np.uint8)
+        PIL.fromarray(arr).save(str(d / ("%06d.jpg" % i)), quality=95)
+    lazy, labels = datasets.load_celeba_split(str(d), "test")
+    assert labels is None and len(lazy) == 202599 - 182638 + 1 and lazy.shape == (None, 64, 64, 3)
+    batch = lazy[0:3]
+    assert batch.shape == (3, 64, 64, 3) and np.array_equal(batch[1], lazy[1]) and np.array_equal(lazy[[2, 0]][0], batch[2])
+    g = datasets.to_generator_range(batch, "celeba")
+    assert g.min() >= -1 and g.max() <= 1
+    with open(str(d / "list_attr_celeba.txt"), "w") as f:
+        f.write("202599\n5_o_Clock_Shadow Male Young\n")
+        for i in range(1, 202600):
+            f.write("%06d.jpg %d %d %d\n" % (i, -1, 1 if i % 3 == 0 else -1, 1))
+    _, lab = datasets.load_celeba_split(str(d), "val", attribute="gender")
+    assert lab.shape == (182637 - 162771 + 1,) and lab[0] == (1 if 162771 % 3 == 0 else 0) and set(lab.tolist()) == {0, 1}
+    with pytest.raises(ValueError):
+        datasets.load_celeba_split(str(d), "all")
