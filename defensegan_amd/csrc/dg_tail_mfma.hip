@@ -924,6 +924,32 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
                 colofs[c3][aw] = (kw > 4 || ow < 0 || ow >= 32) ? 15 : ow * CE16_PITCH + kw * 3 + co;
             }
         }
+        // All 54 candidate taps of this thread's 6 outputs are read first and waited for once; left alone hipcc reads, waits
+        // and sums output by output (6 exposed LDS round trips while two other workgroups of the CU hammer the LDS).  The
+        // A fragments of the GEMM phase are dead by now, so the registers are there.  Sums keep their order.
+        float tv[6][9];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int il = tailw ? 6 + r / 3 : r;                  // wave-uniform
+            const int c3 = tailw ? r % 3 : 0;
+            const int i = 8 * band + il;
+            const int kh0 = (i + 1) & 1;
+#pragma unroll
+            for (int ah = 0; ah < 3; ++ah) {
+                const int kh = kh0 + 2 * ah;
+                const int oh = (i + 1 - kh) >> 1;
+                const bool skip = kh > 4 || oh < 0 || oh >= 32;     // uniform; a skipped row reads slot 0 and is not summed
+                const int lr = skip ? 2 : oh - oh_lo;
+                const float* pu = sP + (((CE16_BASE >> (5 * lr)) & 31) + (skip ? 0 : kh)) * CE16_UNIT;
+#pragma unroll
+                for (int aw = 0; aw < 3; ++aw) tv[r][ah * 3 + aw] = pu[tailw ? colofs[c3][aw] : colofs[0][aw]];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) asm volatile("" : "+v"(tv[r][t9]));
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int il = tailw ? 6 + r / 3 : r;                  // wave-uniform
@@ -936,12 +962,8 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
                 const int kh = kh0 + 2 * ah;
                 const int oh = (i + 1 - kh) >> 1;
                 if (kh > 4 || oh < 0 || oh >= 32) continue;          // uniform
-                const int lr = oh - oh_lo;
-                const float* pu = sP + (((CE16_BASE >> (5 * lr)) & 31) + kh) * CE16_UNIT;
 #pragma unroll
-                for (int aw = 0; aw < 3; ++aw) {
-                    sacc += pu[tailw ? colofs[c3][aw] : colofs[0][aw]];
-                }
+                for (int aw = 0; aw < 3; ++aw) sacc += tv[r][ah * 3 + aw];
             }
             // tanh(v) = sign(v) * (1 - t) / (1 + t), t = exp(-2|v|): absolute error <= 2 ulp(1)
             const float v = sacc + (tailw ? bias[c3] : bias[0]);
