@@ -54,14 +54,13 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     long long tr0 = 0;
     if (g.trace) tr0 = wall_clock64();
 
-    const ClassDesc cd = g.cls[jb.cls];
-    const int s_cnt = cd.pos_count;
-    const unsigned magic = cd.magic;
+    const int s_cnt = jb.pos_count;
+    const unsigned magic = jb.magic;
     const int m_valid = jb.m_valid;
     // M row r of the job -> (latent row n_first + q, position j)
     auto split = [&](int r, int& q, int& j) {
         const unsigned jj = (unsigned)(jb.j_first + r);
-        q = magic ? (int)__umulhi(jj, magic) : (int)jj;
+        q = (int)__umulhi(jj << 1, magic);             // jj / s, magic = ceil(2^31 / s): exact for jj < 2^20, branch-free for s = 1
         j = (int)jj - q * s_cnt;
     };
 
@@ -77,7 +76,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         const int rc = r < m_valid ? r : m_valid - 1;              // ragged M: clamp loads, mask stores
         int q, j;
         split(rc, q, j);
-        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + g.pos_a[cd.pos_begin + j]) * 4u + (unsigned)c * 16u;
+        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + g.pos_a[jb.pos_begin + j]) * 4u + (unsigned)c * 16u;
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
@@ -94,17 +93,15 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int chunks_per_tap = g.kch / BK;
-    const int n_taps = cd.nchunks / chunks_per_tap;
-    const int nchunks = cd.nchunks;
-    const TapEntry* taps = g.taps + cd.tap_begin;
+    const int n_taps = jb.n_taps;
+    const int nchunks = jb.nchunks;
+    const TapEntry* taps = g.taps + jb.tap_begin;
 
     // Staging plan: the slots of chunk c+1 are issued BETWEEN the MFMA groups of chunk c (slot s rides with k-step s % 4).
     int ld_tap = 0, ld_k = 0;
     TapEntry te_nxt = n_taps > 0 ? taps[n_taps > 1 ? 1 : 0] : TapEntry{0, 0};
-    const TapEntry te0 = n_taps > 0 ? taps[0] : TapEntry{0, 0};
-    int cur_a = __builtin_amdgcn_readfirstlane(te0.a_off);
-    int cur_w = __builtin_amdgcn_readfirstlane(te0.w_off);
+    int cur_a = jb.tap0_a_off;                 // the first tap rides in the job record
+    int cur_w = jb.tap0_w_off;
     int aoff = 0, woff = 0;                    // operand byte offsets of the chunk being staged (SGPRs)
     auto next_chunk_offsets = [&]() {
         aoff = (cur_a + ld_k) * 4;
@@ -159,7 +156,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
             ovalid[i][p] = r < m_valid;
             int q, j;
             split(ovalid[i][p] ? r : 0, q, j);
-            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + g.pos_out[cd.pos_begin + j]);
+            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + g.pos_out[jb.pos_begin + j]);
         }
 
     // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk.
@@ -188,8 +185,12 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     }
     if (nchunks > 0) {
         next_chunk_offsets();
+        // the filter slots need nothing but the job record: they go out while the position-table loads that the A slots'
+        // addresses wait for are still in flight
 #pragma unroll
-        for (int s = 0; s < NS; ++s) issue_slot(s, smem);
+        for (int s = SA; s < NS; ++s) issue_slot(s, smem);
+#pragma unroll
+        for (int s = 0; s < SA; ++s) issue_slot(s, smem);
     }
     // One K chunk: wait for its operands, then 4 k-steps; the fragments of k-step kk+1 are read before the MFMAs of kk, and
     // the next chunk's DMA (or, in the LAST chunk of a ReluGrad tile, the gate prefetch) rides between the MFMA groups.

@@ -163,7 +163,7 @@ BatchedPlan make_batched(const LayerPlan& p) {
         cd.pos_count = (int)members[c].size();
         cd.tap_begin = (int)b.taps.size();
         cd.nchunks = (int)sigs[c].size() * cpt;
-        cd.magic = cd.pos_count == 1 ? 0u : (unsigned)(((1ULL << 32) + (unsigned)cd.pos_count - 1) / (unsigned)cd.pos_count);
+        cd.magic = (unsigned)(((1ULL << 31) + (unsigned)cd.pos_count - 1) / (unsigned)cd.pos_count);
         for (const auto& m : members[c]) { b.pos_a.push_back(m.first); b.pos_out.push_back(m.second); }
         for (const auto& t : sigs[c]) b.taps.push_back(TapEntry{t.first, t.second});
         b.cls.push_back(cd);
@@ -253,6 +253,14 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         j.n_first = (int)(pc.m0 / s);
         j.j_first = (int)(pc.m0 % s);
         j.m_valid = pc.rows;
+        const ClassDesc& cd = p.cls[pc.cls];
+        j.pos_begin = cd.pos_begin;
+        j.pos_count = cd.pos_count;
+        j.tap_begin = cd.tap_begin;
+        j.nchunks = cd.nchunks;
+        j.magic = cd.magic;
+        j.n_taps = cd.nchunks / (p.kch / 32);
+        if (cd.nchunks > 0) { j.tap0_a_off = p.taps[cd.tap_begin].a_off; j.tap0_w_off = p.taps[cd.tap_begin].w_off; }
         out.push_back(j);
     }
     return out;

@@ -25,7 +25,7 @@ struct ClassDesc {
     int pos_count;       // s: positions in the class
     int tap_begin;       // first entry of this class in the tap table (a_off relative to the row's pos_a base, >= 0)
     int nchunks;         // K chunks (32 floats each) of every tile of the class = taps * kch / 32
-    unsigned magic;      // ceil(2^32 / s) for the n = m / s split (0 when s == 1)
+    unsigned magic;      // ceil(2^31 / s): m / s = mulhi(2 * m, magic) for m < 2^20 (also for s == 1)
     int pad[3];
 };
 struct JobDesc {         // one workgroup = one job: (class, M range, column range, tile shape)
@@ -35,6 +35,12 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     int n_first;         // latent row of the job's first M row
     int j_first;         // position index (inside the class) of the job's first M row
     int m_valid;         // valid M rows of the job (<= tile height)
+    // copy of the job's ClassDesc and of its first tap: one 64-byte scalar load brings everything the workgroup needs before
+    // its first operand DMA (a separate class record was one more dependent L2 round trip at every job start)
+    int pos_begin, pos_count, tap_begin, nchunks;
+    unsigned magic;
+    int tap0_a_off, tap0_w_off;
+    int n_taps;          // nchunks / (kch / 32)
     int pad[2];
 };
 

@@ -115,7 +115,7 @@ void dgp2_apply(void* h, const double* A, const double* W, const double* bias, d
         const int n_taps = cd.nchunks / (p.kch / 32);
         for (int r = 0; r < jb.m_valid; ++r) {
             const unsigned jj = (unsigned)(jb.j_first + r);
-            const int q = cd.magic ? (int)(((unsigned long long)jj * cd.magic) >> 32) : (int)jj;
+            const int q = (int)(((unsigned long long)(jj << 1) * cd.magic) >> 32);
             const int j = (int)jj - q * cd.pos_count;
             const long long n = (long long)jb.n_first + q;
             for (int c = 0; c < bn; ++c) {
