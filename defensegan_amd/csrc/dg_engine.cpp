@@ -132,6 +132,8 @@ struct dg_handle {
     long long* d_job_trace = nullptr;
     std::string job_trace_op;
     int tail_dbg = 0;
+    int gemm_prio = 0;       // wg_priority mode of the GEMM launches (dg_device.h): measured, no gain; off
+    int tail_prio = 0;       // ... of the CelebA tail launches
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
     int tail_bwd_persist = 512;
@@ -204,6 +206,13 @@ void prof_collect(dg_handle* h) {
         (void)hipEventDestroy(p.e1);
     }
     h->pending.clear();
+}
+
+// forget every tuned job list (an option that changes how the lists are built or timed was set)
+void drop_job_lists(dg_handle* h) {
+    for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
+    for (auto* vec : {&h->Fd, &h->Bd})
+        for (auto& op : *vec) { for (auto& jl : op.jobs) (void)hipFree(jl.d_jobs); op.jobs.clear(); }
 }
 
 void free_batched(GemmOp& op) {
@@ -368,6 +377,7 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
     a.trace = (h->d_job_trace && op.name == h->job_trace_op) ? h->d_job_trace : nullptr;
+    a.prio = h->gemm_prio;
     return a;
 }
 
@@ -450,20 +460,23 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                  hipMemcpyAsync(scratch, Out, out_bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
             out = scratch;
         }
-        for (size_t i = 0; ok && i < cands.size(); ++i) {
-            Cand& c = cands[i];
-            if (!upload_jobs(c.jl, c.jobs)) { ok = false; break; }
-            const dg::GemmArgs a = gemm_args(h, op, c.jl, A, out);
-            // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
-            // two events holds no host submission gaps; short layers are repeated more often.
-            const int reps = std::max(2, std::min(16, (int)(1500.0 / std::max(c.jl.predicted_us, 1.0))));
+        // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
+        // two events holds no host submission gaps; short layers are repeated more often.
+        auto time_list = [&](const JobList& jl, int scale, float* ms_out) {
+            const dg::GemmArgs a = gemm_args(h, op, jl, A, out);
+            const int reps = scale * std::max(2, std::min(16, (int)(1500.0 / std::max(jl.predicted_us, 1.0))));
             dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e0, s);
             for (int rep = 0; rep < reps; ++rep) dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e1, s);
             float ms = 0.f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { ok = false; break; }
-            c.ms = ms / reps;
+            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
+            *ms_out = ms / reps;
+            return true;
+        };
+        for (size_t i = 0; ok && i < cands.size(); ++i) {
+            Cand& c = cands[i];
+            ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
         }
         if (ok) {
             for (size_t i = 0; i < cands.size(); ++i)
@@ -588,6 +601,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.do_backward = tail_backward ? 1 : 0;
         t.dbg = h->tail_dbg;
         t.bwd_bands = h->tail_bwd_bands;
+        t.prio = h->tail_prio;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
             ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
@@ -1107,6 +1121,17 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->tail_bwd_bands = atoi(value);
         return DG_OK;
     }
+    if (k == "gemm_prio" || k == "tail_prio") {
+        const int v = atoi(value);
+        if (v < 0 || v > 3) return fail(DG_E_INVALID, "%s: 0..3", key);
+        if (k == "gemm_prio") {
+            HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipDeviceSynchronize());
+            h->gemm_prio = v;
+            drop_job_lists(h);
+        } else h->tail_prio = v;
+        return DG_OK;
+    }
     if (k == "tail_dbg") {
         h->tail_dbg = atoi(value);
         return DG_OK;
@@ -1123,9 +1148,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.tune") h->job_tune = v != 0.0;
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
-        for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
-        for (auto* vec : {&h->Fd, &h->Bd})
-            for (auto& op : *vec) { for (auto& jl : op.jobs) (void)hipFree(jl.d_jobs); op.jobs.clear(); }
+        drop_job_lists(h);
         return DG_OK;
     }
     if (k == "job_trace") {      // value = op name ("F2"); read back with dg_debug_read("job_trace") (int64 viewed as floats)

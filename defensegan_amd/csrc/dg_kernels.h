@@ -54,6 +54,7 @@ struct GemmArgs {
     int n_jobs;
     int min_level;           // smallest shape code among the jobs (0 = the list holds full tiles)
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
+    int prio;                // wave priority per workgroup slot (see wg_priority); 0 = all equal
 };
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
@@ -97,6 +98,7 @@ struct CelebaTailArgs {
     int fwd16;           // forward MFMA tail: 1 = 16x16x4 kh-aligned formulation (F6p = its pack), 0 = 32x32x2
     long long* trace;    // optional per-workgroup phase cycle totals [grid][8] (persistent backward tail), or nullptr
     int bwd_persist;     // backward MFMA tail: > 0 = persistent pipelined kernel with this many workgroups
+    int prio;            // wave priority per workgroup slot (see wg_priority); 0 = all equal
 };
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // dg_tail_mfma.hip
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s);

@@ -6,30 +6,46 @@ namespace dg {
 // ---- ApplyMomentum (tf.train.MomentumOptimizer, non-Nesterov; gan.py:389-391, 416-417) ------------
 //   g = sum_s part[n][s][d]  (split-K partials of dz = da1 . W^T, fixed summation order)
 //   m <- momentum*m + g ;  z <- z - lr*m
+// One thread owns 4 consecutive latent components of one row; the partials of up to 8 slices are fetched before the first add
+// (the adds keep the slice order: bit-identical for any nsplit grouping).
 __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ z, float* __restrict__ m,
                                                               const float* __restrict__ part, int nsplit,
-                                                              long long n_rows, int latent, float lr,
+                                                              long long n_quads, int latent, float lr,
                                                               float momentum, float* __restrict__ dz_out) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long total = n_rows * latent;
-    if (i >= total) return;
-    const long long n = i / latent;
-    const int d = (int)(i - n * latent);
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    const unsigned qrow = (unsigned)latent >> 2;
+    const long long n = q / qrow;
+    const int d = (int)(q - n * qrow) << 2;
     const float* p = part + n * (long long)nsplit * latent + d;
-    float g = 0.f;
-    for (int s = 0; s < nsplit; ++s) g += p[(long long)s * latent];
-    if (dz_out) { dz_out[i] = g; return; }
-    const float mm = momentum * m[i] + g;
-    m[i] = mm;
-    z[i] = z[i] - lr * mm;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s0 + s < nsplit) v[s] = *reinterpret_cast<const float4*>(p + (long long)(s0 + s) * latent);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s0 + s < nsplit) { g.x += v[s].x; g.y += v[s].y; g.z += v[s].z; g.w += v[s].w; }
+    }
+    const long long i = n * latent + d;
+    if (dz_out) { dz_out[i] = g.x; dz_out[i + 1] = g.y; dz_out[i + 2] = g.z; dz_out[i + 3] = g.w; return; }   // caller's pointer: no alignment assumed
+    const float4 m0 = *reinterpret_cast<const float4*>(m + i);
+    const float4 z0 = *reinterpret_cast<const float4*>(z + i);
+    float4 mm, zz;
+    mm.x = momentum * m0.x + g.x; mm.y = momentum * m0.y + g.y; mm.z = momentum * m0.z + g.z; mm.w = momentum * m0.w + g.w;
+    zz.x = z0.x - lr * mm.x; zz.y = z0.y - lr * mm.y; zz.z = z0.z - lr * mm.z; zz.w = z0.w - lr * mm.w;
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(z + i) = zz;
 }
 
 void launch_momentum_update(float* z, float* m, const float* part, int nsplit, int64_t n_rows, int latent,
                             float lr, float momentum, float* dz_out, hipStream_t s) {
-    const long long total = (long long)n_rows * latent;
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(momentum_update_kernel, dim3(grid), dim3(256), 0, s, z, m, part, nsplit,
-                       (long long)n_rows, latent, lr, momentum, dz_out);
+    const long long n_quads = (long long)n_rows * (latent >> 2);          // latent % 64 == 0 (dg_create)
+    if (n_quads == 0) return;
+    const unsigned grid = (unsigned)((n_quads + 255) / 256);
+    hipLaunchKernelGGL(momentum_update_kernel, dim3(grid), dim3(256), 0, s, z, m, part, nsplit, n_quads, latent, lr,
+                       momentum, dz_out);
 }
 
 // ---- selection: first argmin over the R restarts of each image, then gather (gan.py:438-449) ------

@@ -16,6 +16,7 @@
 //   CelebA (dataset_models.py:160-163): 8 bands per latent row; forward bands own 8 output rows (6 input rows
 //          incl. halo), backward bands own 4 input rows; da6 is parked in HBM between the two kernels.
 #include "dg_kernels.h"
+#include "dg_device.h"
 
 namespace dg {
 
@@ -761,6 +762,10 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
 // (all that fits next to two P buffers): 225 us, the DMA latency sits on every step's critical path; (b) 8 waves, next
 // band's A fragments prefetched into registers by fragment-shaped global loads: 211 us, the single GEMM wave per SIMD
 // spends longer issuing its 16 loads than multiplying.  Both were bit-identical to this kernel and removed.
+// Round 2: (c) all five units' filter fragments requested up front (80 registers, no memory wait inside the GEMM phase):
+// 217 us -- the kernel is bound by VMEM issue bursts, not by the per-unit filter round trip; (d) distinct wave priorities
+// per resident workgroup (wg_priority) to stagger the three workgroups' phases: 190-193 us.  Phase costs (tail_dbg): without
+// the gather 153 us, without the GEMM phase 64 us, without the staging DMA 161 us.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int CE16_PITCH = 17;
 constexpr int CE16_UNIT = 32 * CE16_PITCH;                 // floats per (row, kh) unit
@@ -781,6 +786,7 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     float* sP = reinterpret_cast<float*>(smem);                // [20][32][17], aliases the staging area
     constexpr int MAINF = (6 * ROWB > CE16_UNITS * CE16_UNIT * 4 ? 6 * ROWB : CE16_UNITS * CE16_UNIT * 4) / 4;
     float* sred = sP + MAINF;
+    wg_priority(a.prio);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 3, band = blockIdx.x & 7;
@@ -1038,6 +1044,7 @@ template <int C>
 __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTailArgs a, int n_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sg0 = reinterpret_cast<float*>(smem);                // two images [11][68][3]
+    wg_priority(a.prio);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fh = lane >> 5;

@@ -51,3 +51,11 @@ for c in np.unique(chunks):
     m = chunks == c
     print("  chunks %3d: %5d jobs, duration mean %.1f us (min %.1f, max %.1f), first start %.1f, last end %.1f"
           % (c, m.sum(), d[m].mean(), d[m].min(), d[m].max(), s_us[m].min(), e_us[m].max()))
+# HW_ID fields (gfx9 layout): wave slot 3:0, SIMD 5:4, CU 11:8, SE 15:13, workgroup slot on the CU (TG_ID) 19:16
+tg = (hwid >> 16) & 15
+cu = ((hwid >> 8) & 15) | (((hwid >> 13) & 7) << 4)
+print("workgroup slots (HW_ID.TG_ID) seen: %s" % dict(zip(*np.unique(tg, return_counts=True))))
+prio = ((hwid >> 16) & 3)
+for pr in np.unique(prio):
+    m = prio == pr
+    print("  slot & 3 = %d: %5d jobs, mean duration per chunk %.3f us" % (pr, m.sum(), (d[m] / np.maximum(chunks[m], 1)).mean()))
