@@ -180,6 +180,9 @@ def main():
                     help="configs[4] shape: one step = a defended evaluation of --images images sharded over the ranks")
     ap.add_argument("--images", type=int, default=10000, help="--strong: images in the evaluated list")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
+    ap.add_argument("--use_bn", action="store_true",
+                    help="USE_BN: True variant of the generator (batch-statistics Batchnorm after every hidden layer, "
+                         "tflib/ops/batchnorm.py:80-93); not a BASELINE config (the shipped cfgs have USE_BN: False)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,8 +211,9 @@ def main():
     R = args.rec_rr or R
     L = args.rec_iters or L
     a = archs.make_arch(arch)
-    params = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=0.0)
-    gan = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim},
+    params = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=0.0, use_bn=args.use_bn,
+                                bn_jitter=0.2 if args.use_bn else 0.0)
+    gan = dataset_gan_dict[arch](cfg={"USE_BN": bool(args.use_bn), "LATENT_DIM": a.latent_dim, "NET_DIM": a.net_dim},
                                  test_mode=True, rec_rr=R, rec_iters=L, rec_lr=10.0, device=local_rank)
     assert gan.set_weights(params) == []
     for kv in args.opt:
@@ -283,15 +287,15 @@ def main():
         value = units_per_step * args.steps / dt
         flop_img = archs.flop_per_image(a, R, max(L, 1))
         path_tflops = value * flop_img / 1e12 / world           # per GPU
-        kernels, roofline = roofline_from_profile(prof, args.workload, B, R, path_tflops)
+        kernels, roofline = roofline_from_profile(prof, args.workload + ("_bn" if args.use_bn else ""), B, R, path_tflops)
         cfgno = 4 if args.strong else {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload]
         if args.strong:
             wl = ("%s whitebox-FGSM-like eps=0.3 evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
                   "(BASELINE configs[4]); images sharded contiguously over %d rank(s), one all_gather of (labels, preds, "
                   "diffs)" % (arch, args.images, L, R, B, world))
         else:
-            wl = ("%s L=%d R=%d batch=%d fp32 (BASELINE configs[%d]); synthetic tflib-init weights gain %.1f, "
-                  "x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B, cfgno, gain))
+            wl = ("%s L=%d R=%d batch=%d fp32 (BASELINE configs[%d]%s); synthetic tflib-init weights gain %.1f, "
+                  "x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B, cfgno, " with USE_BN: True" if args.use_bn else "", gain))
         res = {
             "metric": "projected images/sec at L=%d,R=%d (%s)" % (L, R, "MNIST 28x28" if a.arch_id == 0 else "CelebA 64x64"),
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -309,7 +313,7 @@ def main():
         else:
             loss = out["loss"].view(B, R).min(dim=1).values
             res["mean_best_loss"] = round(float(loss.mean().item()), 6)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.use_bn:
             res["cpu_baseline"] = cpu_baseline(arch, params, x[:16].cpu().numpy(), R, L)
         print(json.dumps(res), flush=True)
     if distributed:

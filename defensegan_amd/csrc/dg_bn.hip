@@ -3,61 +3,122 @@
 // variance), y = (x - mean) * rsqrt(var + 1e-5) * scale + offset; is_training / moving averages are ignored.
 // An activation buffer is viewed as [rows, C] (rows = latent rows x spatial positions, C = channels, or
 // rows = latent rows, C = 4096 features for BN1).  All kernels are HBM-bound streaming passes:
-//   partial column sums in float64 (one workgroup per block of rows) -> finalize (float64) -> apply.
+//   partial column sums in float64 (<= 1024 row blocks x column groups of 1024) -> finalize (float64) -> apply.
 // Forward keeps xhat for the backward:  da = (scale*rstd) * (dy - mean(dy) - xhat * mean(dy*xhat)).
+//
+// Layout of the streaming passes (gfx950): a thread owns 4 consecutive channels (b128 loads), the C/4 channel quads of a row
+// sit on adjacent lanes (a wave reads whole 256 B .. 1 KB runs), the remaining lanes of the workgroup take different rows
+// ("row lanes"), and every thread keeps 4 rows in flight before it starts adding.  Sums are float64 from the first add, so
+// the order in which rows are visited does not show in the float32 statistics.
 #include "dg_kernels.h"
 
 namespace dg {
 
-constexpr int BN_RB = 128;       // rows per partial-sum workgroup
+constexpr int BN_MAX_BLOCKS = 1024;  // row blocks of the partial sums (upper bound; bn_part is sized for it)
+constexpr int BN_MIN_ROWS = 32;      // rows per block, at least
+constexpr int BN_COLS = 1024;        // channels per workgroup (256 threads x 4)
+constexpr int BN_FSPLIT = 16;        // finalize: threads per channel
 
-// part[blk][0][c] = sum_r a[r][c];  part[blk][1][c] = sum_r a[r][c] * (b ? b[r][c] : a[r][c])
+static inline long long bn_rows_per_block(long long rows) {
+    const long long r = (rows + BN_MAX_BLOCKS - 1) / BN_MAX_BLOCKS;
+    return r < BN_MIN_ROWS ? BN_MIN_ROWS : r;
+}
+
+// part[blk][0][c] = sum_r a[r][c];  part[blk][1][c] = sum_r a[r][c] * (b ? b[r][c] : a[r][c])      (rows of block blk)
+template <bool HAS_B>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         double* __restrict__ part, long long rows, int C) {
-    __shared__ double red[2][256];
+                                                         double* __restrict__ part, long long rows, int C,
+                                                         long long rows_per_blk) {
+    __shared__ double red[8][256];
     const int tid = threadIdx.x;
-    const int cpt = C < 256 ? C : 256;          // columns per pass
-    const int rs = 256 / cpt;                   // row sub-lanes when C < 256
-    const int c_in = tid % cpt, rsub = tid / cpt;
-    const long long r0 = (long long)blockIdx.x * BN_RB;
-    const long long r1 = r0 + BN_RB < rows ? r0 + BN_RB : rows;
-    for (int c0 = 0; c0 < C; c0 += cpt) {
-        const int c = c0 + c_in;
-        double s1 = 0.0, s2 = 0.0;
-        if (rsub < rs) {
-            for (long long r = r0 + rsub; r < r1; r += rs) {
-                const float v = a[r * C + c];
-                const float w = b ? b[r * C + c] : v;
-                s1 += (double)v;
-                s2 += (double)v * (double)w;
+    const int cw = C < BN_COLS ? C : BN_COLS;              // channels this workgroup covers
+    const int quads = cw >> 2;                             // threads per row
+    const int lanes = 256 / quads;                         // row lanes (>= 1)
+    const int q = tid % quads, rl = tid / quads;
+    const int c = blockIdx.y * BN_COLS + 4 * q;
+    const bool live = rl < lanes && c < C;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < rows ? r0 + rows_per_blk : rows;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (live) {
+        const float* pa = a + c;
+        const float* pb = HAS_B ? b + c : nullptr;
+        long long r = r0 + rl;
+        for (; r + 3LL * lanes < r1; r += 4LL * lanes) {   // 4 rows in flight
+            float4 v[4], w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = *reinterpret_cast<const float4*>(pa + (r + (long long)u * lanes) * C);
+                if (HAS_B) w[u] = *reinterpret_cast<const float4*>(pb + (r + (long long)u * lanes) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!HAS_B) w[u] = v[u];
+                s1[0] += (double)v[u].x; s2[0] += (double)v[u].x * (double)w[u].x;
+                s1[1] += (double)v[u].y; s2[1] += (double)v[u].y * (double)w[u].y;
+                s1[2] += (double)v[u].z; s2[2] += (double)v[u].z * (double)w[u].z;
+                s1[3] += (double)v[u].w; s2[3] += (double)v[u].w * (double)w[u].w;
             }
         }
-        if (rs > 1) {
-            red[0][tid] = s1; red[1][tid] = s2;
-            __syncthreads();
-            if (rsub == 0) {
-                for (int k = 1; k < rs; ++k) { s1 += red[0][k * cpt + c_in]; s2 += red[1][k * cpt + c_in]; }
-            }
-            __syncthreads();
+        for (; r < r1; r += lanes) {
+            const float4 v = *reinterpret_cast<const float4*>(pa + r * C);
+            const float4 w = HAS_B ? *reinterpret_cast<const float4*>(pb + r * C) : v;
+            s1[0] += (double)v.x; s2[0] += (double)v.x * (double)w.x;
+            s1[1] += (double)v.y; s2[1] += (double)v.y * (double)w.y;
+            s1[2] += (double)v.z; s2[2] += (double)v.z * (double)w.z;
+            s1[3] += (double)v.w; s2[3] += (double)v.w * (double)w.w;
         }
-        if (rsub == 0) {
-            part[((long long)blockIdx.x * 2 + 0) * C + c] = s1;
-            part[((long long)blockIdx.x * 2 + 1) * C + c] = s2;
+    }
+    if (lanes > 1) {                                        // fold the row lanes (fixed order)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[e][tid] = s1[e]; red[4 + e][tid] = s2[e]; }
+        __syncthreads();
+        if (rl == 0) {
+            for (int k = 1; k < lanes; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1[e] += red[e][k * quads + q]; s2[e] += red[4 + e][k * quads + q]; }
         }
+    }
+    if (rl == 0 && c < C) {
+        double* p1 = part + ((long long)blockIdx.x * 2 + 0) * C + c;
+        double* p2 = part + ((long long)blockIdx.x * 2 + 1) * C + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p1[e] = s1[e]; p2[e] = s2[e]; }
     }
 }
 
 // forward: stats[0][c] = mean, stats[1][c] = rstd = 1/sqrt(var + eps)
 // backward: stats[0][c] = mean(dy), stats[1][c] = mean(dy * xhat)
+// 16 channels per workgroup, 16 threads per channel: thread j of a channel adds blocks j, j+16, ... (4 loads in flight), the
+// 16 sums are folded in LDS in a fixed order.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblk, long long rows, int C,
                                                           float* __restrict__ stats, int forward) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const int cl = tid & 15, j = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nblk; ++k) {
-        s1 += part[((long long)k * 2 + 0) * C + c];
-        s2 += part[((long long)k * 2 + 1) * C + c];
+    if (c < C) {
+        int k = j;
+        for (; k + 3 * BN_FSPLIT < nblk; k += 4 * BN_FSPLIT) {
+            double x1[4], x2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x1[u] = part[((long long)(k + u * BN_FSPLIT) * 2 + 0) * C + c];
+                x2[u] = part[((long long)(k + u * BN_FSPLIT) * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1 += x1[u]; s2 += x2[u]; }
+        }
+        for (; k < nblk; k += BN_FSPLIT) {
+            s1 += part[((long long)k * 2 + 0) * C + c];
+            s2 += part[((long long)k * 2 + 1) * C + c];
+        }
     }
+    red[0][tid] = s1; red[1][tid] = s2;
+    __syncthreads();
+    if (j != 0 || c >= C) return;
+    for (int k = 1; k < BN_FSPLIT; ++k) { s1 += red[0][k * 16 + cl]; s2 += red[1][k * 16 + cl]; }
     const double m1 = s1 / (double)rows, m2 = s2 / (double)rows;
     if (forward) {
         double var = m2 - m1 * m1;
@@ -113,21 +174,27 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ d
     *reinterpret_cast<float4*>(dy + i) = o;
 }
 
-int bn_num_blocks(int64_t rows) { return (int)((rows + BN_RB - 1) / BN_RB); }
+int bn_max_blocks() { return BN_MAX_BLOCKS; }
+
+static void launch_bn_stats(const float* a, const float* b, const BnArgs& args, float* stats, int forward, hipStream_t s) {
+    const long long rpb = bn_rows_per_block(args.rows);
+    const int nblk = (int)((args.rows + rpb - 1) / rpb);
+    const dim3 grid((unsigned)nblk, (unsigned)((args.C + BN_COLS - 1) / BN_COLS));
+    if (b) hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
+    else hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((args.C + 15) / 16), dim3(256), 0, s, args.part, nblk, (long long)args.rows,
+                       args.C, stats, forward);
+}
 
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s) {
-    const int nblk = bn_num_blocks(a.rows);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(256), 0, s, a.a, (const float*)nullptr, a.part, (long long)a.rows, a.C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a.part, nblk, (long long)a.rows, a.C, a.fstats, 1);
+    launch_bn_stats(a.a, nullptr, a, a.fstats, 1, s);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);
 }
 
 void launch_bn_backward(const BnArgs& a, hipStream_t s) {
-    const int nblk = bn_num_blocks(a.rows);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nblk), dim3(256), 0, s, a.a, (const float*)a.xhat, a.part, (long long)a.rows, a.C);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((a.C + 255) / 256), dim3(256), 0, s, a.part, nblk, (long long)a.rows, a.C, a.bstats, 0);
+    launch_bn_stats(a.a, a.xhat, a, a.bstats, 0, s);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.bstats, a.scale, total, a.C);

@@ -349,7 +349,7 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         a.buf = h->act[d];
         if (a.has_bn) {
             HIP_TRY(hipMalloc(&a.xhat, cap * a.row_floats * sizeof(float)));
-            const size_t need = (size_t)dg::bn_num_blocks(cap * a.bn_rows) * 2 * a.bn_C;
+            const size_t need = (size_t)dg::bn_max_blocks() * 2 * a.bn_C;
             if (need > part_doubles) part_doubles = need;
         }
     }
@@ -542,7 +542,9 @@ dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
 // forward chain at the current h->z; fills activations, loss, (y when want_y); when tail_backward the tail also
 // leaves the gradient w.r.t. the last GEMM activation in place.  x points at image 0 of the CALL (row0 / R
 // images are skipped inside).  With use_bn the whole call is one row group (batch statistics couple all rows).
-int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool tail_backward, bool prof) {
+// want_loss: the per-row loss is only read after the last step (selection) and by dg_loss_grad; the CelebA tail leaves
+// per-band partial sums, whose reduction is skipped when nobody reads the result.
+int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool want_loss, bool tail_backward, bool prof) {
     const int n_rows = g.n_rows;
     hipStream_t s = g.s;
     const int64_t r0 = g.row0;
@@ -607,7 +609,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
             ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
             dg::launch_celeba_tail_fwd_mfma(t, s);
         }
-        dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
+        if (want_loss) dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
         if (tail_backward) {
             ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
             dg::launch_celeba_tail_bwd_mfma(t, s);
@@ -961,7 +963,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
         for (int gi = 0; gi < ngroups; ++gi) {
             const RowGroup& g = grp[gi];
-            rc = run_forward(h, x, g, R, /*want_y=*/last, /*tail_backward=*/!last, prof);
+            rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
             if (rc) return rc;
             if (last) continue;
             rc = run_backward(h, g, prof);
@@ -997,7 +999,7 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)N * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     // the loss is discarded here: every row is compared with one all-zero image (R = N -> image 0)
     RowGroup g; g.n_rows = N; g.s = s;
-    rc = run_forward(h, h->xzero, g, /*R=*/N, /*want_y=*/true, /*tail_backward=*/false, false);
+    rc = run_forward(h, h->xzero, g, /*R=*/N, /*want_y=*/true, /*want_loss=*/false, /*tail_backward=*/false, false);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)N * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
@@ -1018,7 +1020,7 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     RowGroup g; g.n_rows = n_rows; g.s = s;
-    rc = run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*tail_backward=*/out_dz != nullptr, false);
+    rc = run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*want_loss=*/out_loss != nullptr, /*tail_backward=*/out_dz != nullptr, false);
     if (rc) return rc;
     if (out_y) HIP_TRY(hipMemcpyAsync(out_y, h->y, (size_t)n_rows * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));

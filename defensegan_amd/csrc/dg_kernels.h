@@ -121,7 +121,7 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
 struct BnArgs {
     float* a;            // fwd: pre-activation in, [relu](bn(a)) out | bwd: masked dy in, da out (in place)
     float* xhat;         // [rows, C] normalised activations (written by fwd, read by bwd)
-    double* part;        // [nblk, 2, C] scratch
+    double* part;        // [nblk <= bn_max_blocks(), 2, C] scratch
     float* fstats;       // [2, C] mean, rstd (written by fwd)
     float* bstats;       // [2, C] mean(dy), mean(dy*xhat) (written by bwd)
     const float* scale;  // [C]
@@ -129,7 +129,7 @@ struct BnArgs {
     int64_t rows;
     int C;
 };
-int bn_num_blocks(int64_t rows);
+int bn_max_blocks();        // row blocks of the partial sums, upper bound: part holds bn_max_blocks() * 2 * C doubles
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
 void launch_bn_backward(const BnArgs& a, hipStream_t s);
 

@@ -72,11 +72,12 @@ def test_celeba_reconstruct_matches_golden():
     assert (out["idx"] == g["idx"]).all()
 
 
-@pytest.mark.parametrize("arch", ["mnist", "celeba"])
-def test_bn_forward_backward_vs_oracle(arch):
-    """use_bn=True: batch statistics at inference (batchnorm.py:80-93) couple all B*R rows."""
+@pytest.mark.parametrize("arch,B,R", [("mnist", 6, 3), ("celeba", 6, 3), ("mnist", 64, 3)])
+def test_bn_forward_backward_vs_oracle(arch, B, R):
+    """use_bn=True: batch statistics at inference (batchnorm.py:80-93) couple all B*R rows.  The 192-row case has more
+    than 32 * 1024 statistics rows in the last BN layer (37 632): row blocks longer than the minimum, 1018 partial sums
+    per channel in the finalize pass."""
     O = _oracle()
-    B, R = 6, 3
     gan, p = make_gan(arch, gain=2.0, bias_range=0.1, use_bn=True)
     a = archs.make_arch(arch)
     x = _targets(arch, B, 3)
@@ -90,9 +91,16 @@ def test_bn_forward_backward_vs_oracle(arch):
     np.testing.assert_allclose(y, yo, rtol=0, atol=2e-5)
     np.testing.assert_allclose(loss, lo, rtol=5e-5)
     # a ReLU kink anywhere perturbs every row through the statistics: compare in aggregate
-    assert _rel(dz, go) < 5e-3, _rel(dz, go)
-    med = np.median(np.abs(dz - go).max(axis=1) / np.abs(go).max())
-    assert med < 5e-5, med
+    row_err = np.abs(dz - go).max(axis=1) / np.abs(go).max()
+    if B * R <= 32:
+        assert _rel(dz, go) < 5e-3, _rel(dz, go)
+        assert np.median(row_err) < 5e-5, np.median(row_err)
+    else:
+        # 192 rows x 50 176 gated activations: some gate sits within float32 rounding of zero.  The float32 run of the
+        # NumPy oracle on this input differs from its float64 run by 1.3e-2 in one row (a flipped gate), by <= 1.3e-4 in
+        # every other row (all rows move a little: the flip shifts the batch statistics), median 8e-5
+        assert np.median(row_err) < 3e-4, np.median(row_err)
+        assert (row_err < 1e-3).mean() >= 0.98 and row_err.max() < 5e-2, np.sort(row_err)[-4:]
 
 
 def test_bn_reconstruct_short_horizon_vs_oracle():
