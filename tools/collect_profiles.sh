@@ -12,6 +12,9 @@ BUILD=$(python -c "import bench; print(bench.build_id())")
 echo "build $BUILD" > $OUT/build.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o mnist -- python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_mnist_under_rocprof.json 2> $OUT/stats_mnist.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o celeba -- python bench.py --workload celeba --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_celeba_under_rocprof.json 2> $OUT/stats_celeba.err
+# the USE_BN: True variant (not a BASELINE config): bench line + kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o mnist_use_bn -- python bench.py --use_bn --steps 5 --warmup 2 > $OUT/bench_mnist_use_bn_under_rocprof.json 2> $OUT/stats_mnist_use_bn.err
+python bench.py --workload celeba --use_bn --steps 3 --warmup 1 > $OUT/bench_celeba_use_bn.json 2>> $OUT/stats_mnist_use_bn.err
 for W in mnist celeba; do
   CMD="python bench.py --workload $W --steps 1 --warmup 1 --rec_iters 4 --no-cpu-baseline --no-profile"
   rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc -o ${W}_fetch -- $CMD > /dev/null 2> $OUT/pmc_${W}_fetch.err
