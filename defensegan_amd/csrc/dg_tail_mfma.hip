@@ -765,7 +765,12 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
 // Round 2: (c) all five units' filter fragments requested up front (80 registers, no memory wait inside the GEMM phase):
 // 217 us -- the kernel is bound by VMEM issue bursts, not by the per-unit filter round trip; (d) distinct wave priorities
 // per resident workgroup (wg_priority) to stagger the three workgroups' phases: 190-193 us.  Phase costs (tail_dbg): without
-// the gather 153 us, without the GEMM phase 64 us, without the staging DMA 161 us.
+// the gather 153 us, without the GEMM phase 64 us, without the staging DMA 161 us.  Phase trace of wave 0 (TRACE instantiation,
+// tools/tail_trace.py fwd): a workgroup lives 29.6 k cycles (12.9 us; 13.3 workgroups per slot): issuing its x / DMA / filter
+// loads 15.8 %, waiting for the staged rows 5.7 %, fragment reads 4.2 %, barrier 5.9 %, the five GEMM units 26.0 % (7.7 k cycles
+// for 5.1 k cycles of MFMA issue), barrier 2.5 %, gather + tanh + stores 30.2 %, loss reduction and exit 9.8 %.  Three
+// workgroups per CU (LDS) = 3 waves per SIMD overlap these serial phases to 51 % MFMA occupancy.  (e) a persistent form that
+// keeps all filter fragments in registers needs 80 + 64 + 16 registers before addressing: spills at 3 waves per SIMD.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int CE16_PITCH = 17;
 constexpr int CE16_UNIT = 32 * CE16_PITCH;                 // floats per (row, kh) unit
@@ -777,7 +782,10 @@ constexpr int CE16_UNITS = 20;
 // lr4 -> 15 (kh 0..2 -> 15..17), lr5 -> 14
 constexpr unsigned CE16_BASE = 15u | (9u << 5) | (0u << 10) | (5u << 15) | (15u << 20) | (14u << 25);
 
-template <int C>
+// TRACE (option tail_trace with tail_dbg = 8; tools/tail_trace.py fwd): wave 0 of workgroups 3072 .. 6143 (past the launch's
+// ramp) records the cycle counter at the phase boundaries.  A separate instantiation: the 18 extra registers must not reach
+// the product kernel (126 + 8 registers: 3 waves per SIMD).
+template <int C, bool TRACE>
 __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KK = C / 16;                                  // channel groups of 16 (4 MFMAs each)
@@ -790,6 +798,10 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 3, band = blockIdx.x & 7;
+    const bool tr = TRACE && a.trace != nullptr && wave == 0 && blockIdx.x >= 3072 && blockIdx.x < 6144;
+    long long tc[TRACE ? 9 : 1];
+    auto mark = [&](int i) { if constexpr (TRACE) { if (tr) tc[i] = (long long)__builtin_readcyclecounter(); } };
+    mark(0);
     const int b = n / a.R;
     const float* hrow = a.h5 + (long long)n * (1024 * C);
     const int oh_lo = 4 * band - 1;
@@ -857,7 +869,9 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     // A fragments: lane (i = lane & 15, g = lane >> 4) of position tile m holds channels 16*kk + 4*g + e
     const int fi = lane & 15, fg = lane >> 4;
     f32x4v avA[2][KK], avB[2][KK];
+    mark(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mark(2);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -871,7 +885,9 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
             avB[m][kk] = vb;
         }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mark(3);
     __syncthreads();                                            // staging is dead: P may overwrite it
+    mark(4);
 
     // ---- GEMM: 5 (row, kh) units per wave, each 2 position tiles x KK*4 MFMAs (two independent accumulation chains);
     // the next unit's filter fragments are in flight while the current one runs -------------------------------------------
@@ -905,7 +921,9 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
             else if (inB) unit(avB, wc, lrB, kh);
         }
     }
+    mark(5);
     __syncthreads();
+    mark(6);
 
     // ---- gather (taps of matching parity) + tanh + loss + da6 ---------------------------------------------------------
     float* grow = a.g6 + (long long)n * 12288;
@@ -982,11 +1000,19 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
             if (yrow) yrow[oi] = y;
         }
     }
+    mark(7);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
     if (lane == 0) sred[wave] = sq;
     __syncthreads();
     if (tid == 0) a.loss_part[(long long)n * 8 + band] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    if constexpr (TRACE) {
+        if (tr && lane == 0) {
+            mark(8);
+            long long* o = a.trace + (long long)(blockIdx.x - 3072 + 1024) * 8;     // rows 1024 .. 4095 of the [4096][8] buffer
+            for (int i = 0; i < 8; ++i) o[i] = tc[i + 1] - tc[i];
+        }
+    }
 }
 
 // NB consecutive 4-input-row bands per workgroup: the filter fragments (76 registers) and the launch/ramp cost are
@@ -1086,7 +1112,7 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
     int buf = 0;
     // optional phase timing (wave 0): [0] fetch issue, [1] gather reads + MFMA issue, [2] store issue,
     // [3] wait for the prefetch + park, [4] absolute start (100 MHz), [5] items, [6] cycles, [7] 100 MHz ticks
-    const bool tr = a.trace != nullptr;
+    const bool tr = a.trace != nullptr && a.dbg != 8;          // dbg 8: the forward kernel owns the trace buffer
     long long ph[5] = {0, 0, 0, 0, 0}, t_begin = tr ? (long long)__builtin_readcyclecounter() : 0, nit = 0;
     const long long w_begin = tr ? (long long)wall_clock64() : 0;     // constant 100 MHz counter
     while (item < n_items) {
@@ -1156,12 +1182,14 @@ void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
     if (attr.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
     }
     if (a.fwd16) {
-        if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
-        else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        if (a.C == 64 && a.trace && a.dbg == 8) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, true>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        else if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
         return;
     }
     if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
