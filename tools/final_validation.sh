@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/r3z; O=gpurun_out/r3z
+timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+bash tools/collect_profiles.sh r3p > gpurun_out/r3p.log 2>&1
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_mnist_driver_cmd.json 2> $O/b.err
+python bench.py --workload celeba --steps 5 --warmup 2 > $O/bench_celeba.json 2>> $O/b.err
+python bench.py --workload fmnist --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_fmnist.json 2>> $O/b.err
+python bench.py --strong --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_strong.json 2>> $O/b.err
+python bench.py --batch 50 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_b50.json 2>> $O/b.err
+for f in $O/bench_*.json; do echo $f; python -c "import json,sys; d=json.load(open(sys.argv[1])); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['path_frac'], d['roofline']['traffic'])" $f; done
