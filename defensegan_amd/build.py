@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdefensegan_hip.so")
 SOURCES = ["dg_engine.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_tail_mfma.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
-HEADERS = ["dg_kernels.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
+HEADERS = ["dg_kernels.h", "dg_device.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
 ARCH = "gfx950"
 
 

@@ -98,7 +98,7 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
 
 
-@pytest.mark.parametrize("arch,opts", [("celeba", {"tail_fwd16": 0}), ("mnist", {"nsplit": 4}), ("mnist", {"nsplit": 16})])
+@pytest.mark.parametrize("arch,opts", [("celeba", {"tail_fwd16": 0}), ("mnist", {"nsplit": 4}), ("mnist", {"nsplit": 8})])
 def test_reordered_formulations_agree_to_rounding(arch, opts):
     a = archs.make_arch(arch)
     B, R = 6, 3
