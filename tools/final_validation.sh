@@ -1,5 +1,6 @@
 mkdir -p gpurun_out/r3z; O=gpurun_out/r3z
-timeout 900 python -m pytest tests -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+# TESTS="tests/a.py tests/b.py" restricts the test step (default: the whole -m gpu suite)
+timeout 900 python -m pytest ${TESTS:-tests} -x -q -m gpu > $O/pytest.log 2>&1; tail -3 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 bash tools/collect_profiles.sh r3p > gpurun_out/r3p.log 2>&1
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_mnist_driver_cmd.json 2> $O/b.err
