@@ -1,0 +1,91 @@
+"""CPU: the host-side arithmetic of bench.py (no GPU, no timing): the roofline object built from an event profile, the
+algorithmic FLOP model behind `value -> TFLOP/s`, and the rule that `roofline.traffic` is only ever quoted from a PMC file
+collected on exactly this build of the kernels."""
+import json
+import os
+
+import pytest
+
+import bench
+from defensegan_amd import archs
+
+
+def test_flop_model_matches_the_survey_numbers():
+    """SURVEY appendix C / DESIGN 4: valid-tap MACs per latent row -- MNIST 524 288 + 7 372 800 + 8 388 608 + 67^2 * 64."""
+    a = archs.make_arch("mnist")
+    macs = archs.fwd_macs_per_row(a)
+    assert macs == 128 * 4096 + 7372800 + 8388608 + 67 * 67 * 64
+    # L forwards, L - 1 useful backwards, R restarts per image
+    assert archs.flop_per_image(a, 10, 200) == 10 * 399 * 2.0 * macs
+    assert archs.flop_per_image(a, 1, 1) == 2.0 * macs
+    c = archs.make_arch("celeba")                           # 524 288 + 9 469 952 + 11 214 848 + 24 285 184 + 4 732 608
+    assert archs.fwd_macs_per_row(c) == 524288 + 9469952 + 11214848 + 24285184 + 4732608 == 50226880
+    # the per-image figures SURVEY quotes to six digits
+    assert abs(archs.flop_per_image(c, 10, 200) - 4.00811e11) < 1e6
+    assert abs(archs.flop_per_image(a, 10, 200) - 1.32252e11) < 1e6
+
+
+def test_roofline_object_from_a_profile():
+    prof = [
+        {"name": "F2@gemm_batched_kernel<0, 3, 1>", "launches": 200, "ms": 200 * 0.275, "flops": 200 * 3.77e10},
+        {"name": "B2@gemm_batched_kernel<0, 3, 1>", "launches": 199, "ms": 199 * 0.280, "flops": 199 * 3.77e10},
+        {"name": "F3@gemm_batched_kernel<1, 2, 1>", "launches": 200, "ms": 200 * 0.311, "flops": 200 * 4.29e10},
+        {"name": "UPD@momentum_update_kernel", "launches": 199, "ms": 199 * 0.007, "flops": 0.0},
+        {"name": "never@launched", "launches": 0, "ms": 0.0, "flops": 0.0},
+    ]
+    kernels, r = bench.roofline_from_profile(prof, "not-a-profiled-workload", 256, 10, path_tflops=128.0)
+    assert [k["name"] for k in kernels] == ["F2", "B2", "F3", "UPD"]
+    assert r["kernel"] == "gemm_batched_kernel<0, 3, 1>"                 # most total time, grouped by symbol as rocprofv3 does
+    avg_us = (200 * 275.0 + 199 * 280.0) / 399
+    assert abs(r["avg_launch_us"] - avg_us) < 0.01
+    assert abs(r["achieved"] - 3.77e10 / (avg_us * 1e-6) / 1e12) < 0.02
+    assert abs(r["frac"] - r["achieved"] / 157.3) < 1e-3 and r["peak"] == 157.3 and r["bound"] == "mfma"
+    assert r["traffic"] is None and r["traffic_source"] is None          # nothing collected for that workload
+    assert abs(r["path_frac"] - 128.0 / 157.3) < 1e-3
+    assert abs(r["sum_kernel_ms_per_step"] - sum(p["ms"] for p in prof)) < 1e-3
+    # no profile (e.g. --no-profile, --strong): the whole-path rate stands in
+    kernels, r = bench.roofline_from_profile([], "mnist", 256, 10, path_tflops=100.0)
+    assert kernels == [] and r["kernel"] is None and r["achieved"] == 100.0 and r["traffic"] is None
+
+
+def test_traffic_is_quoted_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
+    sym = "gemm_batched_kernel<0, 3, 1>"
+    doc = {"build": bench.build_id(), "mnist": {sym: {"bytes_per_launch": 123}}, "celeba": {sym: {"bytes_per_launch": 7}}}
+    prof_dir = tmp_path / "profiles"
+    prof_dir.mkdir()
+    (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.traffic_for("mnist", sym, 256, 10) == (123, "profiles/" + bench.TRAFFIC_FILE)
+    assert bench.traffic_for("fmnist", sym, 256, 10)[0] == 123           # same architecture and row count
+    assert bench.traffic_for("celeba", sym, 128, 10)[0] == 7
+    assert bench.traffic_for("mnist", sym, 50, 10) == (None, None)       # another row count: not measured
+    assert bench.traffic_for("mnist", "some_other_kernel", 256, 10)[0] is None
+    assert bench.traffic_for("mnist_bn", sym, 256, 10) == (None, None)   # --use_bn runs quote nothing
+    doc["build"] = "0" * 12                                             # collected on other kernel sources
+    (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
+    assert bench.traffic_for("mnist", sym, 256, 10) == (None, None)
+
+
+def test_build_id_covers_every_kernel_source_and_header():
+    """The id must change whenever anything compiled into the library changes: every file under csrc/ is hashed."""
+    from defensegan_amd import build
+    listed = {os.path.basename(f) for f in build.SOURCES + build.HEADERS}
+    on_disk = {f for f in os.listdir(build.CSRC) if f.endswith((".hip", ".cpp", ".h"))}
+    assert on_disk <= listed, sorted(on_disk - listed)
+    assert len(bench.build_id()) == 12 and int(bench.build_id(), 16) >= 0
+
+
+def test_committed_traffic_file_is_well_formed():
+    path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", bench.TRAFFIC_FILE)
+    if not os.path.exists(path):
+        pytest.skip("no PMC traffic file committed")
+    with open(path) as fh:
+        doc = json.load(fh)
+    assert len(doc["build"]) == 12
+    for wl in ("mnist", "celeba"):
+        assert doc[wl], wl
+        for sym, rec in doc[wl].items():
+            assert rec["bytes_per_launch"] > 0 and rec["launches_profiled"] > 0, (wl, sym)
+            # FETCH_SIZE (KB, doubled per the gfx950 note) + WRITE_SIZE (KB), per launch
+            total = (2.0 * rec["fetch_kb_raw"] + rec["write_kb"]) * 1024.0
+            assert abs(total - rec["bytes_per_launch"]) <= 0.02 * total, (wl, sym)
