@@ -62,7 +62,8 @@ def traffic_for(workload, kernel, B, R):
         return None, None
     with open(path) as fh:
         doc = json.load(fh)
-    if doc.get("build") != build_id():
+    # one build id per workload ("builds"): the two sets may have been collected at different times
+    if doc.get("builds", {}).get(key, doc.get("build")) != build_id():
         return None, None
     return doc.get(key, {}).get(kernel, {}).get("bytes_per_launch"), "profiles/" + TRAFFIC_FILE
 

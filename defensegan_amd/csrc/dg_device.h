@@ -11,10 +11,12 @@ namespace dg {
 // The priority comes from the workgroup's slot on the CU (HW_ID.TG_ID, bits 19:16 on gfx9): uniform over the waves of a
 // workgroup (waves of one workgroup never wait for each other across priorities), distinct among the residents.
 //   mode 1: slot & 3      mode 2: 3 * (slot & 1)      mode 3: 3 - (slot & 3)
-// Measured on MI355X (options gemm_prio / tail_prio, round 2): the priorities do take effect (with mode 1 a job in slot 3 runs
-// 1.54 us per K chunk, one in slot 0 2.17 us; equal priorities 1.77-2.02 us) but the launches take the same time to within
-// noise (MNIST 980.7 vs 980.8 img/s; CelebA forward tail 186 -> 190-193 us): the kernels are throughput-bound, not phase-
-// locked.  Off by default; kept as an experiment switch.
+// Measured on MI355X (round 2): the priorities do take effect (in the GEMM kernel, mode 1, a job in slot 3 ran 1.54 us per K
+// chunk, one in slot 0 2.17 us; equal priorities 1.77-2.02 us) but the launches take the same time to within noise (MNIST
+// 980.7 vs 980.8 img/s; CelebA forward tail 186 -> 190-193 us): the kernels are throughput-bound, not phase-locked.  The
+// hook was REMOVED from the GEMM kernel again: even switched off, its presence changed the register allocation of the
+// ReluGrad-epilogue instantiation (109 / 71 instead of 107 / 81 VGPRs / SGPRs) and cost 1.5-2.5 % on B3 / B2.  It stays in
+// the CelebA tails (option tail_prio, off), whose timings did not move.
 __device__ __forceinline__ void wg_priority(int mode) {
     if (mode == 0) return;
     unsigned hwid;

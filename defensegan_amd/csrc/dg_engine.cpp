@@ -135,8 +135,7 @@ struct dg_handle {
     long long* d_job_trace = nullptr;
     std::string job_trace_op;
     int tail_dbg = 0;
-    int gemm_prio = 0;       // wg_priority mode of the GEMM launches (dg_device.h): measured, no gain; off
-    int tail_prio = 0;       // ... of the CelebA tail launches
+    int tail_prio = 0;       // wg_priority mode of the CelebA tail launches (dg_device.h): measured, no gain; off
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
     int tail_bwd_persist = 512;
@@ -380,7 +379,6 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
     a.trace = (h->d_job_trace && op.name == h->job_trace_op) ? h->d_job_trace : nullptr;
-    a.prio = h->gemm_prio;
     return a;
 }
 
@@ -1152,15 +1150,10 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->tail_bwd_bands = atoi(value);
         return DG_OK;
     }
-    if (k == "gemm_prio" || k == "tail_prio") {
+    if (k == "tail_prio") {
         const int v = atoi(value);
         if (v < 0 || v > 3) return fail(DG_E_INVALID, "%s: 0..3", key);
-        if (k == "gemm_prio") {
-            HIP_TRY(hipSetDevice(h->device));
-            HIP_TRY(hipDeviceSynchronize());
-            h->gemm_prio = v;
-            drop_job_lists(h);
-        } else h->tail_prio = v;
+        h->tail_prio = v;
         return DG_OK;
     }
     if (k == "tail_dbg") {

@@ -18,7 +18,6 @@
 #include <type_traits>
 
 #include "dg_kernels.h"
-#include "dg_device.h"
 
 namespace dg {
 
@@ -292,7 +291,6 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
 template <int FAM, int MODE, int MINLEVEL>
 __global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    wg_priority(g.prio);
     const JobDesc jb = g.jobs[blockIdx.x];
     const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
     if constexpr (FAM == 0) {

@@ -54,7 +54,6 @@ struct GemmArgs {
     int n_jobs;
     int min_level;           // smallest shape code among the jobs (0 = the list holds full tiles)
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
-    int prio;                // wave priority per workgroup slot (see wg_priority); 0 = all equal
 };
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);

@@ -61,6 +61,11 @@ def test_traffic_is_quoted_only_for_the_build_it_was_measured_on(tmp_path, monke
     assert bench.traffic_for("mnist", sym, 50, 10) == (None, None)       # another row count: not measured
     assert bench.traffic_for("mnist", "some_other_kernel", 256, 10)[0] is None
     assert bench.traffic_for("mnist_bn", sym, 256, 10) == (None, None)   # --use_bn runs quote nothing
+    doc["builds"] = {"mnist": bench.build_id(), "celeba": "0" * 12}     # per-workload ids: CelebA collected on other sources
+    (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
+    assert bench.traffic_for("mnist", sym, 256, 10)[0] == 123
+    assert bench.traffic_for("celeba", sym, 128, 10) == (None, None)
+    del doc["builds"]
     doc["build"] = "0" * 12                                             # collected on other kernel sources
     (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
     assert bench.traffic_for("mnist", sym, 256, 10) == (None, None)
@@ -81,8 +86,8 @@ def test_committed_traffic_file_is_well_formed():
         pytest.skip("no PMC traffic file committed")
     with open(path) as fh:
         doc = json.load(fh)
-    assert len(doc["build"]) == 12
     for wl in ("mnist", "celeba"):
+        assert len(doc.get("builds", {}).get(wl, doc.get("build"))) == 12
         assert doc[wl], wl
         for sym, rec in doc[wl].items():
             assert rec["bytes_per_launch"] > 0 and rec["launches_profiled"] > 0, (wl, sym)
