@@ -46,9 +46,10 @@ WORKLOADS = {
 
 
 def build_id():
-    """First 12 hex digits of the SHA-256 over the HIP/C++ sources the loaded library was built from."""
+    """First 12 hex digits of the SHA-256 over the HIP/C++ sources the loaded library was built from (comments and layout
+    excluded: defensegan_amd.build.code_digest)."""
     from defensegan_amd import build as _b
-    return _b._digest()[:12]
+    return _b.code_digest()[:12]
 
 
 def traffic_for(workload, kernel, B, R):

@@ -27,10 +27,46 @@ def _hipcc() -> str:
 
 
 def _digest() -> str:
+    """SHA-256 over the raw bytes of every source and header: the rebuild stamp (any edit rebuilds)."""
     h = hashlib.sha256()
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
+    return h.hexdigest()
+
+
+def _strip_comments(text: str) -> str:
+    """C/C++ source without its comments, whitespace runs collapsed (string and character literals are left alone)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":                                      # literal: copy through the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+def code_digest() -> str:
+    """Identity of the CODE the library is built from (bench.build_id(), profiles/): as _digest() but over the sources with
+    comments and layout removed, so that correcting a comment does not orphan the measurements taken on that code."""
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "r", encoding="utf-8") as fh:
+            h.update(_strip_comments(fh.read()).encode("utf-8"))
+        h.update(b"\0")
     return h.hexdigest()
 
 

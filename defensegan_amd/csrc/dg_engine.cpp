@@ -141,7 +141,7 @@ struct dg_handle {
     int tail_bwd_persist = 512;
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
-    int two_streams = 0;   // number of concurrent row groups; measured +3 % only: off keeps kernel timings comparable with rocprof
+    int two_streams = 0;   // number of concurrent row groups; measured +0.4 .. +1.3 % at 2560 rows, -10 % at 500: off (also keeps kernel timings comparable with rocprof)
     int two_stream_min_rows = 1024;
     static constexpr int kMaxGroups = 4;
     hipStream_t side_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};

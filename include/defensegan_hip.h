@@ -133,7 +133,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "jobs.slack"       > 0 fixes the cutting threshold of the job lists (dg_plan.h build_jobs; 1e30 = whole tiles only)
  *   "jobs.min_level"   >= 0 forces every list to start cut to halves (1) / quarters (2)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
- *   "nsplit"           split-K factor of the Linear backward (default 8)
+ *   "nsplit"           split-K factor of the Linear backward (default 16)
  *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd16"       CelebA forward tail: 1 = 16x16x4 kh-aligned (default), 0 = 32x32x2

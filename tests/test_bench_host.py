@@ -80,6 +80,30 @@ def test_build_id_covers_every_kernel_source_and_header():
     assert len(bench.build_id()) == 12 and int(bench.build_id(), 16) >= 0
 
 
+def test_build_id_ignores_comments_and_layout_only():
+    """The id is taken over the sources without comments (a corrected comment must not orphan the measurements made on
+    that code) -- and over nothing less: the stripped text equals what gcc's own comment removal leaves."""
+    import shutil
+    import subprocess
+    from defensegan_amd import build
+    s = build._strip_comments
+    assert s('int a = 1; // c\n/* b\n b */ const char* u = "http://x/*y*/"; char q = \'"\'; // t\n') == \
+        'int a = 1; const char* u = "http://x/*y*/"; char q = \'"\';'
+    assert s("a/**/b") == "a b" and s("x = 1;   \n\n  y = 2;") == "x = 1; y = 2;"
+    assert s('p = "a \\" // not a comment"; // yes') == 'p = "a \\" // not a comment";'
+    assert s("int a = 1;") != s("int a = 2;")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc to compare with")
+    for f in build.SOURCES + build.HEADERS:
+        path = os.path.join(build.CSRC, f)
+        ref = subprocess.run([gcc, "-fpreprocessed", "-dD", "-E", "-P", "-x", "c++", path], capture_output=True, text=True,
+                             check=True).stdout
+        with open(path, encoding="utf-8") as fh:
+            mine = s(fh.read())
+        assert mine.replace("#pragma once ", "", 1) == " ".join(ref.split()), f      # gcc consumes the pragma
+
+
 def test_committed_traffic_file_is_well_formed():
     path = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles", bench.TRAFFIC_FILE)
     if not os.path.exists(path):
