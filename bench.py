@@ -8,6 +8,8 @@ step   : one pass of the hot path (dg_reconstruct) over one batch of B synthetic
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher: re-executes itself as the line above; exits non-zero when the node
+                                         has fewer than N GPUs -- it never prints an n_gpus it did not run on)
 
 --strong: BASELINE configs[4] shape instead -- a step is ONE defended evaluation of a fixed list of 10 000 synthetic
 images (FGSM-like inputs, classifier model A), sharded contiguously over the ranks (gan_defense.shard_range), projected
@@ -21,6 +23,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -167,6 +171,41 @@ def roofline_from_profile(prof, workload, B, R, path_tflops):
     return kernels, roofline
 
 
+def self_launch_command(argv, n_gpus, port):
+    """The command `python bench.py --gpus N ...` turns itself into when N > 1 and no launcher set WORLD_SIZE: one rank
+    per GPU of this node under torch.distributed.run (backend nccl = RCCL), rendezvous on 127.0.0.1 (the container's
+    hostname may not resolve).  `argv` = the bench's own arguments, passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def resolve_ranks(n_gpus, env, device_count):
+    """(world, rank, local_rank, relaunch) for `--gpus n_gpus` under the environment `env` on a node with `device_count`
+    GPUs.  relaunch = True: this process must re-exec itself under torch.distributed.run (N > 1 asked for, no launcher
+    present).  Raises SystemExit with a message -- never a silent 1-GPU run -- when the request cannot be honoured."""
+    if n_gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1 (got %d)" % n_gpus)
+    if device_count < n_gpus:
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node; refusing to report a %d-GPU "
+                         "number from fewer devices" % (n_gpus, device_count, n_gpus))
+    if "WORLD_SIZE" not in env:
+        return (1, 0, 0, False) if n_gpus == 1 else (n_gpus, 0, 0, True)
+    world, rank, local_rank = int(env["WORLD_SIZE"]), int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (n_gpus, world))
+    if not (0 <= local_rank < device_count):
+        raise SystemExit("bench.py: LOCAL_RANK=%d but %d GPU(s) are visible" % (local_rank, device_count))
+    return world, rank, local_rank, False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,11 +226,14 @@ def main():
                          "tflib/ops/batchnorm.py:80-93); not a BASELINE config (the shipped cfgs have USE_BN: False)")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    world, rank, local_rank, relaunch = resolve_ranks(args.gpus, os.environ, torch.cuda.device_count())
+    if relaunch:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", "8")
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(self_launch_command(sys.argv[1:], args.gpus, _free_port()), env=env))
     # DG_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to test it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("DG_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)

@@ -118,3 +118,61 @@ def test_committed_traffic_file_is_well_formed():
             # FETCH_SIZE (KB, doubled per the gfx950 note) + WRITE_SIZE (KB), per launch
             total = (2.0 * rec["fetch_kb_raw"] + rec["write_kb"]) * 1024.0
             assert abs(total - rec["bytes_per_launch"]) <= 0.02 * total, (wl, sym)
+
+
+def test_gpus_n_never_degrades_to_a_one_gpu_run():
+    """`--gpus N` either runs N ranks or exits: launcher present -> WORLD_SIZE must equal N; launcher absent and N > 1 ->
+    the bench re-executes itself under torch.distributed.run; fewer than N devices -> SystemExit, whatever the environment."""
+    r = bench.resolve_ranks
+    assert r(1, {}, 1) == (1, 0, 0, False)
+    assert r(8, {}, 8) == (8, 0, 0, True)                                   # no launcher: relaunch with 8 ranks
+    assert r(2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, 8) == (2, 1, 1, False)
+    assert r(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 1) == (1, 0, 0, False)   # DG_BENCH_FORCE_DIST runs
+    for n, env, ndev in [(8, {}, 1), (2, {}, 0), (8, {"WORLD_SIZE": "1"}, 8), (2, {"WORLD_SIZE": "4"}, 8),
+                         (2, {"WORLD_SIZE": "2", "LOCAL_RANK": "1"}, 1), (0, {}, 1),
+                         (2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "5"}, 4)]:
+        with pytest.raises(SystemExit) as e:
+            r(n, env, ndev)
+        assert "bench.py" in str(e.value)                                   # a message, i.e. a non-zero exit status
+
+
+def test_self_launch_command_is_the_drivers_launch_line():
+    cmd = bench.self_launch_command(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4, 29544)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29544"
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+
+
+def test_gpus_2_on_a_box_with_fewer_gpus_exits_nonzero_with_a_message():
+    """The real command line, as a process: on this CPU-only container (and on a 1-GPU box) `--gpus 2` must fail loudly
+    instead of printing a JSON line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, bench.__file__, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "--gpus 2" in p.stderr and "GPU(s) are visible" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_self_launch_starts_one_rank_per_gpu(tmp_path):
+    """The relaunch line really starts N workers with RANK / LOCAL_RANK / WORLD_SIZE set: run it on a stand-in script
+    (torch.distributed.run, 2 processes, CPU) and read what each rank saw."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text("import os, sys\n"
+                      "open(os.path.join(sys.argv[1], 'rank%s' % os.environ['RANK']), 'w').write("
+                      "'%s %s %s %s' % (os.environ['WORLD_SIZE'], os.environ['LOCAL_RANK'], os.environ['MASTER_ADDR'], ' '.join(sys.argv[2:])))\n")
+    cmd = bench.self_launch_command([str(tmp_path), "--gpus", "2"], 2, bench._free_port())
+    cmd[cmd.index(os.path.abspath(bench.__file__))] = str(script)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert (tmp_path / "rank0").read_text() == "2 0 127.0.0.1 --gpus 2"
+    assert (tmp_path / "rank1").read_text() == "2 1 127.0.0.1 --gpus 2"
