@@ -297,6 +297,9 @@ def main():
             return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
         units_per_step = world * B
 
+    gan.prepare(B)          # workspace + timed job lists: outside the hot call (dg_prepare); the steps below only enqueue
+    if args.strong and (e0 - s0) % B:
+        gan.prepare((e0 - s0) % B)        # the ragged last projection batch of this rank's shard
     for i in range(args.warmup):
         step(i)
     barrier()

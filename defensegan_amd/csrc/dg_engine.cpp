@@ -92,6 +92,8 @@ struct GemmOp {
     const float* bias = nullptr;
 };
 
+constexpr int kJobTraceCap = 65536;
+
 struct ProfEntry {
     std::string name;
     int64_t launches = 0;
@@ -143,9 +145,9 @@ struct dg_handle {
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     int two_streams = 0;   // number of concurrent row groups; measured +0.4 .. +1.3 % at 2560 rows, -10 % at 500: off (also keeps kernel timings comparable with rocprof)
     int two_stream_min_rows = 1024;
-    static constexpr int kMaxGroups = 4;
-    hipStream_t side_stream[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {nullptr, nullptr, nullptr};
+    static constexpr int kMaxGroups = 8;
+    hipStream_t side_stream[kMaxGroups - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
 
     // workspace
     int64_t cap_rows = 0;
@@ -210,6 +212,13 @@ void prof_collect(dg_handle* h) {
     h->pending.clear();
 }
 
+// A failed launch (bad configuration, LDS limit, ...) is reported by the layer it happened in, not at the end of the call.
+int launch_check(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return DG_OK;
+}
+
 // forget every tuned job list (an option that changes how the lists are built or timed was set)
 void drop_job_lists(dg_handle* h) {
     for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
@@ -230,6 +239,10 @@ void free_batched(GemmOp& op) {
 // `base` = the layer planned with one PosEntry per position (bn == ncols)
 int upload_batched(GemmOp& op, const dg::LayerPlan& base) {
     free_batched(op);
+    // the job shapes are 64 / 128 columns wide and the kernel never masks columns or K: anything else would read and write
+    // out of bounds (dg_create's latent_dim % 64 / net_dim % 64 checks guarantee this for the two generators)
+    if (base.ncols % 64 != 0 || base.kch % 32 != 0 || base.kch <= 0)
+        return fail(DG_E_INVALID, "layer %s: %d output columns / K %d per tap (need multiples of 64 / 32)", op.name.c_str(), base.ncols, base.kch);
     op.bplan = dg::make_batched(base);
     op.family = (base.ncols % 128 == 0) ? 0 : 1;
     const dg::BatchedPlan& b = op.bplan;
@@ -378,7 +391,8 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.mode = op.mode;
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
-    a.trace = (h->d_job_trace && op.name == h->job_trace_op) ? h->d_job_trace : nullptr;
+    // the trace buffer holds kJobTraceCap records (one per workgroup): larger launches are not traced
+    a.trace = (h->d_job_trace && op.name == h->job_trace_op && jl.n_jobs <= kJobTraceCap) ? h->d_job_trace : nullptr;
     return a;
 }
 
@@ -401,9 +415,14 @@ bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs) {
 // only), so the choice is purely one of speed: with `job_tune` the candidates are TIMED on the layer's real operands (the
 // launch is repeated on the actual input; an in-place ReluGrad layer writes to a scratch copy of its output) and the fastest
 // is kept; without it the cost model's simulated makespan decides.
-const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, float* Out, hipStream_t s) {
+const JobList* find_jobs(const GemmOp& op, int n_rows) {
     for (const auto& jl : op.jobs)
         if (jl.n_rows == n_rows) return &jl;
+    return nullptr;
+}
+
+const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, float* Out, hipStream_t s) {
+    if (const JobList* have = find_jobs(op, n_rows)) return have;
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     struct Cand { JobList jl; std::vector<dg::JobDesc> jobs; float ms = 0.f; };
@@ -464,7 +483,8 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
         // two events holds no host submission gaps; short layers are repeated more often.
         auto time_list = [&](const JobList& jl, int scale, float* ms_out) {
-            const dg::GemmArgs a = gemm_args(h, op, jl, A, out);
+            dg::GemmArgs a = gemm_args(h, op, jl, A, out);
+            a.trace = nullptr;                       // candidate launches are not the traced ones
             const int reps = scale * std::max(2, std::min(16, (int)(1500.0 / std::max(jl.predicted_us, 1.0))));
             dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e0, s);
@@ -532,16 +552,18 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     return &op.jobs.back();
 }
 
-// One GEMM layer: the job list for this row count (built and, by default, chosen by timing on first use), one launch.
+// One GEMM layer: one launch with the job list prepare_rows() left for this row count.  Nothing here allocates or waits.
 int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
-    const JobList* jl = get_jobs(h, op, n_rows, A, Out, s);
-    if (!jl) return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), n_rows);
+    const JobList* jl = find_jobs(op, n_rows);
+    if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
     const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out);
     char sym[64];
     snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, jl->min_level);
-    ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
-    dg::launch_gemm(op.family, a, s);
-    return DG_OK;
+    {
+        ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
+        dg::launch_gemm(op.family, a, s);
+    }
+    return launch_check(op.name.c_str());
 }
 
 // A row group = a contiguous range of latent rows (whole images) processed on one stream.  Rows are independent
@@ -551,6 +573,71 @@ struct RowGroup {
     int row0 = 0, n_rows = 0;
     hipStream_t s = nullptr;
 };
+
+// Row groups of a call over B images x R restarts (whole images per group; the streams are assigned by the caller).
+int split_groups(const dg_handle* h, int B, int R, RowGroup* grp) {
+    const int n_rows = B * R;
+    int ngroups = 1;
+    grp[0].row0 = 0; grp[0].n_rows = n_rows;
+    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
+        ngroups = h->two_streams < B ? h->two_streams : B;
+        if (ngroups > dg_handle::kMaxGroups) ngroups = dg_handle::kMaxGroups;
+        int b_done = 0;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const int nb = (B - b_done + (ngroups - gi) - 1) / (ngroups - gi);     // images of this group
+            grp[gi].row0 = b_done * R;
+            grp[gi].n_rows = nb * R;
+            b_done += nb;
+        }
+    }
+    return ngroups;
+}
+
+// Everything a call needs before its first kernel: workspace for `cap_rows` latent rows and, for each row count in
+// `rows[0..n)`, the job list of every GEMM layer (built and, with jobs.tune, timed on the layer's own buffers).  This is the
+// only place on the compute path that allocates device memory or waits for the device; once it has run for a row count,
+// calls with that row count only enqueue kernels.  A stream that is being captured cannot be prepared on.
+int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStream_t s) {
+    bool missing = cap_rows > h->cap_rows;
+    const int nd = (int)h->dec.size();
+    auto each_op = [&](auto&& fn) -> int {
+        int rc = fn(h->F1, 0, -1, 0);                 // (op, kind, deconv index)
+        for (int d = 0; !rc && d + 1 < nd; ++d) rc = fn(h->Fd[d], 1, d, 0);
+        for (int d = nd - 2; !rc && d >= 0; --d) rc = fn(h->Bd[d], 2, d, 0);
+        if (!rc) rc = fn(h->B1, 3, -1, 0);
+        return rc;
+    };
+    for (int i = 0; i < n && !missing; ++i)
+        each_op([&](GemmOp& op, int, int, int) { if (!find_jobs(op, rows[i])) missing = true; return 0; });
+    if (!missing) return DG_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(DG_E_STATE, "this call shape has not been prepared and the stream is being captured: call dg_prepare(B, R) "
+                                "before the capture (it allocates workspace and times the job lists)");
+    int rc = ensure_workspace(h, cap_rows);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        const int nr = rows[i];
+        rc = each_op([&](GemmOp& op, int kind, int d, int) {
+            const float* A = kind == 0 ? h->z : kind == 1 ? h->act[d] : kind == 2 ? h->act[d + 1] : h->act[0];
+            float* Out = kind == 0 ? h->act[0] : kind == 1 ? h->act[d + 1] : kind == 2 ? h->act[d] : h->part;
+            if (!get_jobs(h, op, nr, A, Out, s))
+                return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), nr);
+            return (int)DG_OK;
+        });
+        if (rc) return rc;
+    }
+    return DG_OK;
+}
+
+// prepare_rows for a projection call of B images x R restarts: its row groups' sizes
+int prepare_call(dg_handle* h, int B, int R, hipStream_t s) {
+    RowGroup grp[dg_handle::kMaxGroups];
+    const int ng = split_groups(h, B, R, grp);
+    int rows[dg_handle::kMaxGroups];
+    for (int gi = 0; gi < ng; ++gi) rows[gi] = grp[gi].n_rows;
+    return prepare_rows(h, (int64_t)B * R, rows, ng, s);
+}
 
 dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
     dg::BnArgs b;
@@ -611,6 +698,10 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? "T5fb@mnist_tail_pipe_kernel" : "T5fb@mnist_tail_mfma_kernel",
                      (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         dg::launch_mnist_tail_mfma(t, s);
+    }
+    if (h->arch == DG_ARCH_MNIST28) {
+        const int rc2 = launch_check("the MNIST tail (Generator.5 + loss)");
+        if (rc2) return rc2;
     } else {
         dg::CelebaTailArgs t;
         t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
@@ -641,6 +732,8 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
             ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
             dg::launch_celeba_tail_bwd_mfma(t, s);
         }
+        const int rc2 = launch_check("the CelebA tail (Generator.6 + loss)");
+        if (rc2) return rc2;
     }
     return DG_OK;
 }
@@ -960,28 +1053,19 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    rc = ensure_workspace(h, n_rows);
+    rc = prepare_call(h, B, R, s);          // a no-op (no allocation, no wait) once this shape has been prepared
     if (rc) return rc;
     const size_t zbytes = (size_t)n_rows * h->latent * sizeof(float);
     if (z0) HIP_TRY(hipMemcpyAsync(h->z, z0, zbytes, hipMemcpyDeviceToDevice, s));
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
     const int steps = L > 1 ? L : 1;
-    // split the batch (by image) into two row groups on two streams when it is large enough to fill the chip twice
+    // the batch split (by image) into row groups on separate streams (option two_streams)
     RowGroup grp[dg_handle::kMaxGroups];
-    int ngroups = 1;
-    grp[0].row0 = 0; grp[0].n_rows = n_rows; grp[0].s = s;
-    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
-        ngroups = h->two_streams < B ? h->two_streams : B;
-        if (ngroups > dg_handle::kMaxGroups) ngroups = dg_handle::kMaxGroups;
-        int b_done = 0;
-        for (int gi = 0; gi < ngroups; ++gi) {
-            const int nb = (B - b_done + (ngroups - gi) - 1) / (ngroups - gi);     // images of this group
-            grp[gi].row0 = b_done * R;
-            grp[gi].n_rows = nb * R;
-            grp[gi].s = gi == 0 ? s : h->side_stream[gi - 1];
-            b_done += nb;
-        }
+    const int ngroups = split_groups(h, B, R, grp);
+    grp[0].s = s;
+    if (ngroups > 1) {
+        for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = h->side_stream[gi - 1];
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
     }
@@ -1012,6 +1096,23 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     return DG_OK;
 }
 
+int dg_prepare(dg_handle* h, int B, int R, void* stream) {
+    int rc = check_ready(h);
+    if (rc) return rc;
+    int n_rows = 0;
+    rc = check_rows(B, R, &n_rows);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    rc = prepare_call(h, B, R, s);
+    if (rc) return rc;
+    // dg_loss_grad / dg_generate and the profiled (single-group) form of the same shape run all rows as one group
+    rc = prepare_rows(h, n_rows, &n_rows, 1, s);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    return DG_OK;
+}
+
 int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream) {
     int rc = check_ready(h);
     if (rc) return rc;
@@ -1021,7 +1122,7 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    rc = ensure_workspace(h, N);
+    rc = prepare_rows(h, N, &N, 1, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)N * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     // the loss is discarded here: every row is compared with one all-zero image (R = N -> image 0)
@@ -1043,7 +1144,7 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     if (rc) return rc;
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    rc = ensure_workspace(h, n_rows);
+    rc = prepare_rows(h, n_rows, &n_rows, 1, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
     RowGroup g; g.n_rows = n_rows; g.s = s;
@@ -1099,7 +1200,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
-    else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = 65536 * 4 * 2; }
+    else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = (int64_t)kJobTraceCap * 4 * 2; }
     else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
@@ -1115,7 +1216,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
     const std::string k(key);
     if (k == "two_streams") {
-        h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..4)
+        h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
         return DG_OK;
     }
@@ -1177,8 +1278,8 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "job_trace") {      // value = op name ("F2"); read back with dg_debug_read("job_trace") (int64 viewed as floats)
         HIP_TRY(hipSetDevice(h->device));
-        if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)65536 * 4 * sizeof(long long)));
-        HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)65536 * 4 * sizeof(long long)));
+        if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)kJobTraceCap * 4 * sizeof(long long)));
+        HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)kJobTraceCap * 4 * sizeof(long long)));
         h->job_trace_op = value;
         return DG_OK;
     }

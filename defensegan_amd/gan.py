@@ -270,6 +270,21 @@ class DefenseGANBase(object):
             return out
         return rec.cpu().numpy() if was_numpy else rec
 
+    def prepare(self, batch_size=None):
+        """Builds everything ``reconstruct`` needs for batches of ``batch_size`` images (workspace, the per-layer job lists
+        chosen by timing) ahead of the first call -- the counterpart of the reference building its static graph for
+        ``batch_size * rec_rr`` rows (gan.py:345-377).  Optional: an unprepared ``reconstruct`` prepares itself, blocking
+        once per new batch size; after ``prepare`` the call only enqueues work on the stream (dg_prepare)."""
+        self._ensure_handle()
+        if not self.initialized:
+            raise _native.NativeError("generator weights not loaded (load_generator / set_weights)")
+        torch = _torch()
+        dev = torch.device("cuda", self._device)
+        B = int(batch_size or self.test_batch_size)
+        with torch.cuda.device(dev):
+            _native.check(_native.load().dg_prepare(self._handle, B, int(self.rec_rr),
+                                                    torch.cuda.current_stream(dev).cuda_stream))
+
     def reconstruct_dataset(self, splits, checkpoint_dir, batch_size=None, max_num=-1, test_again=False, seed=None):
         """Counterpart of ``reconstruct_dataset`` (gan.py:451-587) for in-memory splits.
 

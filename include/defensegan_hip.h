@@ -86,7 +86,10 @@ int dg_weights_complete(dg_handle* h);
  *   out_idx  [B] int32     selected restart r*(b) in [0,R)  (first minimum, gan.py:438-445)   (may be NULL)
  *   out_loss [B*R]         image_rec_loss of every restart at step L-1                        (may be NULL)
  *   out_z    [B*R, latent] z_{L-1}                                                            (may be NULL)
- *   stream   hipStream_t (NULL = default stream); the call is asynchronous on it
+ *   stream   hipStream_t (NULL = default stream).  Once the call shape (B, R) has been prepared -- by dg_prepare or by an
+ *            earlier call of the same shape -- the call only enqueues kernels and copies on `stream`: it neither allocates
+ *            device memory nor waits for the device, and may be recorded by a stream capture.  The FIRST call of a new shape
+ *            prepares itself and therefore BLOCKS (see dg_prepare); under a stream capture it fails with DG_E_STATE instead.
  *
  * Stateless per call (fresh z / momentum each batch = model_eval_gan's behaviour,
  * /root/reference/utils/gan_defense.py:119); any B >= 1 is accepted (ragged last batch).
@@ -94,6 +97,17 @@ int dg_weights_complete(dg_handle* h);
 int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed, int64_t first_row,
                    int B, int R, int L, float lr, float momentum,
                    float* out_rec, int32_t* out_idx, float* out_loss, float* out_z, void* stream);
+
+/*
+ * Prepares calls of B images x R restarts (no reference counterpart: the reference builds its static graph for exactly
+ * batch_size * rec_rr rows at this point, gan.py:345-377): sizes the workspace for B*R latent rows and builds the job list of
+ * every GEMM layer for this shape -- with "jobs.tune" (default) by timing the candidate lists on the device, ~0.1-0.3 s.
+ * Blocking: allocates, launches timing runs on `stream` and waits for them.  Afterwards dg_reconstruct / dg_loss_grad with
+ * this (B, R) and dg_generate with N = B*R are asynchronous in the strict sense documented at dg_reconstruct.  Shapes stay
+ * prepared until an option that changes the lists is set (at most 16 row counts are kept per layer, oldest dropped first).
+ * Results never depend on which list was chosen (tiles are only cut along M / N): preparing is about latency only.
+ */
+int dg_prepare(dg_handle* h, int B, int R, void* stream);
 
 /* G(z): z [N, latent] -> y [N, H, W, C].  (generator_fn(z, is_training=False), gan.py:399) */
 int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream);
