@@ -12,7 +12,7 @@ step   : one pass of the hot path (dg_reconstruct) over one batch of B synthetic
                                          has fewer than N GPUs -- it never prints an n_gpus it did not run on)
 
 --strong: BASELINE configs[4] shape instead -- a step is ONE defended evaluation of a fixed list of 10 000 synthetic
-images (FGSM-like inputs, classifier model A), sharded contiguously over the ranks (gan_defense.shard_range), projected
+images (FGSM eps = 0.3 inputs from the bare classifier, model A; built untimed), sharded contiguously over the ranks (gan_defense.shard_range), projected
 in batches, with the single all_gather of (labels, preds, diffs) at the end; images/s = 10 000 / wall ("scaling": "strong").
 
 The timed region carries NO instrumentation.  Per-kernel durations for the roofline leg come from ONE extra, untimed
@@ -274,12 +274,22 @@ def main():
         from defensegan_amd import gan_defense, network_builder as nb
         n_total = args.images
         s0, e0 = gan_defense.shard_range(n_total, rank, world)
-        x = torch.cat([make_inputs(gan, a, min(2000, e0 - i), 0, first_image=i) for i in range(s0, e0, 2000)]) \
-            if e0 > s0 else torch.empty((0,) + tuple(a.image_dim), device=dev)
         clf = nb.model_a()
         clf._device = local_rank
         clf.init_like_reference(seed=5)
-        labels = clf.fprop(x)["logits"].argmax(dim=1).cpu().numpy() if e0 > s0 else np.zeros(0, np.int64)
+        # untimed setup, the step BEFORE the path (whitebox.py:198-210): clean images G(z_true) keyed by the global image
+        # index, labels = the classifier's predictions on them, x = FastGradientMethod(classifier).generate(eps = 0.3,
+        # clip [0, 1]) on the bare classifier (the attack is built before the reconstruction layer is attached)
+        fgsm = nb.FastGradientMethod(clf)
+        xs, ls = [], []
+        for i in range(s0, e0, 2000):
+            n_i = min(2000, e0 - i)
+            clean = gan.generate(gan.init_latents(n_i, seed=1000, first_row=i))
+            lab = clf.fprop(clean)["logits"].argmax(dim=1)
+            xs.append(fgsm.generate(clean, eps=0.3, y=lab, clip_min=a.in_lo, clip_max=a.in_hi))
+            ls.append(lab.cpu().numpy())
+        x = torch.cat(xs).contiguous() if xs else torch.empty((0,) + tuple(a.image_dim), device=dev)
+        labels = np.concatenate(ls) if ls else np.zeros(0, np.int64)
         result = {}
 
         def step(i):
@@ -337,7 +347,7 @@ def main():
         kernels, roofline = roofline_from_profile(prof, args.workload + ("_bn" if args.use_bn else ""), B, R, path_tflops)
         cfgno = 4 if args.strong else {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload]
         if args.strong:
-            wl = ("%s whitebox-FGSM-like eps=0.3 evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
+            wl = ("%s whitebox FGSM eps=0.3 (classifier model A, dg_fgsm) evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
                   "(BASELINE configs[4]); images sharded contiguously over %d rank(s), one all_gather of (labels, preds, "
                   "diffs)" % (arch, args.images, L, R, B, world))
         else:

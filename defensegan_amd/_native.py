@@ -11,6 +11,9 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdefensegan_hip.so")
+# same sources built with -DDG_MEASURE (in-kernel traces, phase-removal switches, superseded cross-check kernels): loaded only
+# by tools/ and by the variant tests that ask for it, never by the product path
+MEASURE_LIB_PATH = os.path.join(_HERE, "lib", "libdefensegan_hip_measure.so")
 
 DG_OK = 0
 ABI_VERSION = 1
@@ -48,23 +51,23 @@ SYMBOLS = [
     ("dg_fgsm", _i, [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp]),
 ]
 
-_lib: Optional[C.CDLL] = None
+_libs = {}
 
 
 class NativeError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Loads the in-tree HIP library; raises (never falls back) when it is missing."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(measure: bool = False) -> C.CDLL:
+    """Loads the in-tree HIP library (``measure``: its -DDG_MEASURE build); raises (never falls back) when it is missing."""
+    if measure in _libs:
+        return _libs[measure]
+    path = MEASURE_LIB_PATH if measure else LIB_PATH
+    if not os.path.exists(path):
         raise NativeError(
             "HIP extension missing: %s (run `python -c 'import __graft_entry__ as g; g.build()'` or "
-            "`python defensegan_amd/build.py`); there is no CPU fallback" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "`python defensegan_amd/build.py`); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the library does not export the symbol
         fn.restype = res
@@ -72,11 +75,11 @@ def load() -> C.CDLL:
     v = lib.dg_version()
     if v != ABI_VERSION:
         raise NativeError("ABI version mismatch: library %d, binding %d" % (v, ABI_VERSION))
-    _lib = lib
+    _libs[measure] = lib
     return lib
 
 
-def check(rc: int) -> None:
+def check(rc: int, lib: Optional[C.CDLL] = None) -> None:
     if rc != DG_OK:
-        msg = load().dg_last_error()
+        msg = (lib or load()).dg_last_error()
         raise NativeError("defensegan_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libdefensegan_hip.so")
+# the same sources with -DDG_MEASURE: in-kernel phase traces, phase-removal switches and the superseded tail kernels kept as
+# cross-checks (tools/, tests/test_gpu_variants.py).  Never loaded by the product path.
+LIB_MEASURE = os.path.join(LIBDIR, "libdefensegan_hip_measure.so")
 SOURCES = ["dg_engine.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_tail_mfma.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
 HEADERS = ["dg_kernels.h", "dg_device.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
 ARCH = "gfx950"
@@ -70,32 +73,36 @@ def code_digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.stamp")
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
+def _build_one(lib: str, objdir: str, defines, verbose: bool) -> None:
     hipcc = _hipcc()
-    objs = []
-    objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    procs = []
+    objs, procs = [], []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".", "_") + ".o")
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj, "-I", CSRC]
+               os.path.join(CSRC, src), "-o", obj, "-I", CSRC] + list(defines)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + src)
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Builds the product library and the measurement library (-DDG_MEASURE) from the same sources; returns the product's path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(LIB_MEASURE) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    _build_one(LIB, os.path.join(LIBDIR, "obj"), [], verbose)
+    _build_one(LIB_MEASURE, os.path.join(LIBDIR, "obj_measure"), ["-DDG_MEASURE"], verbose)
     with open(stamp, "w") as fh:
         fh.write(dig)
     return LIB

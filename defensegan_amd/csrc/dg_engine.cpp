@@ -143,6 +143,9 @@ struct dg_handle {
     int tail_bwd_persist = 512;
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
+    // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
+    // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
+    int lr_intended = 0;
     int two_streams = 0;   // number of concurrent row groups; measured +0.4 .. +1.3 % at 2560 rows, -10 % at 500: off (also keeps kernel timings comparable with rocprof)
     int two_stream_min_rows = 1024;
     static constexpr int kMaxGroups = 8;
@@ -391,8 +394,10 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.mode = op.mode;
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
+#ifdef DG_MEASURE
     // the trace buffer holds kJobTraceCap records (one per workgroup): larger launches are not traced
     a.trace = (h->d_job_trace && op.name == h->job_trace_op && jl.n_jobs <= kJobTraceCap) ? h->d_job_trace : nullptr;
+#endif
     return a;
 }
 
@@ -484,7 +489,9 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         // two events holds no host submission gaps; short layers are repeated more often.
         auto time_list = [&](const JobList& jl, int scale, float* ms_out) {
             dg::GemmArgs a = gemm_args(h, op, jl, A, out);
+#ifdef DG_MEASURE
             a.trace = nullptr;                       // candidate launches are not the traced ones
+#endif
             const int reps = scale * std::max(2, std::min(16, (int)(1500.0 / std::max(jl.predicted_us, 1.0))));
             dg::launch_gemm(op.family, a, s);
             (void)hipEventRecord(e0, s);
@@ -690,9 +697,11 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.R = R;
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
-        t.dbg = h->tail_dbg;
         t.pipe = h->tail_pipe;
+#ifdef DG_MEASURE
+        t.dbg = h->tail_dbg;
         t.trace = h->d_tail_trace;
+#endif
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         const bool piped = t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
         ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? "T5fb@mnist_tail_pipe_kernel" : "T5fb@mnist_tail_mfma_kernel",
@@ -706,10 +715,16 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         dg::CelebaTailArgs t;
         t.h5 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
         t.F6 = h->F[nd - 1];
+        t.F6p = h->tail_pack16;
+        t.bwd_persist = h->tail_bwd_persist;
+#ifdef DG_MEASURE
         t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
         t.fwd16 = h->tail_fwd16;
-        t.bwd_persist = h->tail_bwd_persist;
         t.trace = h->d_tail_trace;
+        t.dbg = h->tail_dbg;
+        t.bwd_bands = h->tail_bwd_bands;
+        t.prio = h->tail_prio;
+#endif
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
         t.loss_part = h->loss_part + r0 * 8;
@@ -719,17 +734,22 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.R = R;
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
-        t.dbg = h->tail_dbg;
-        t.bwd_bands = h->tail_bwd_bands;
-        t.prio = h->tail_prio;
         const double macs = 157.0 * 157.0 * last.cin * 3.0;   // valid taps 32 -> 64
         {
+#ifdef DG_MEASURE
             ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
+#else
+            ProfScope ps(h, s, prof, "T6f@celeba_tail_fwd16_kernel", 2.0 * macs * n_rows);
+#endif
             dg::launch_celeba_tail_fwd_mfma(t, s);
         }
-        if (want_loss) dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, s);
+        if (want_loss) dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, h->P, s);
         if (tail_backward) {
+#ifdef DG_MEASURE
             ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
+#else
+            ProfScope ps(h, s, prof, "T6b@celeba_tail_bwd_persist_kernel", 2.0 * macs * n_rows);
+#endif
             dg::launch_celeba_tail_bwd_mfma(t, s);
         }
         const int rc2 = launch_check("the CelebA tail (Generator.6 + loss)");
@@ -981,8 +1001,12 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
                                 const int kappa = tt * 32 + (lane & 31), c = kk * 8 + (lane >> 5) * 4 + e;
                                 if (kappa < nk) pk[(((size_t)tt * kkn + kk) * 64 + lane) * 4 + e] = host[(size_t)kappa * s.cin + c];
                             }
+#ifdef DG_MEASURE      // only the superseded 32-wide CelebA forward tail reads this pack
                 if (!h->tail_pack) HIP_TRY(hipMalloc(&h->tail_pack, pk.size() * sizeof(float)));
                 HIP_TRY(hipMemcpy(h->tail_pack, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+#else
+                (void)pk;
+#endif
                 if (s.cout == 3) {
                     // B fragments of v_mfma_f32_16x16x4_f32, one 16-column tile per filter row kh: column
                     // j = kw*3 + co (< 15) is kappa = 15*kh + j; lane = j + 16*g holds c = 16*kk + 4*g + e.
@@ -1069,9 +1093,11 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
     }
+    const int decay_iter = L > 0 ? (int)std::ceil(0.8 * (double)L) : 1;
     for (int k = 0; k < steps; ++k) {
         const bool last = (k == steps - 1);
         const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
+        const float lr_k = h->lr_intended ? lr * std::pow(0.1f, (float)(k / decay_iter)) : lr;
         for (int gi = 0; gi < ngroups; ++gi) {
             const RowGroup& g = grp[gi];
             rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
@@ -1082,7 +1108,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
             ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
             const int64_t r0 = g.row0;
             dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
-                                       h->nsplit, g.n_rows, h->latent, lr, momentum, nullptr, g.s);
+                                       h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s);
         }
     }
     for (int gi = 1; gi < ngroups; ++gi) {
@@ -1200,8 +1226,10 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
     else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
     else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
+#ifdef DG_MEASURE
     else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = (int64_t)kJobTraceCap * 4 * 2; }
     else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
+#endif
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
         if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
@@ -1220,10 +1248,45 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
         return DG_OK;
     }
+    if (k == "lr_schedule") {
+        const std::string v(value);
+        if (v != "constant" && v != "intended") return fail(DG_E_INVALID, "lr_schedule: 'constant' or 'intended'");
+        h->lr_intended = v == "intended";
+        return DG_OK;
+    }
     if (k == "two_stream_min_rows") {
         h->two_stream_min_rows = atoi(value);
         return DG_OK;
     }
+    if (k == "tail_pipe") {
+        h->tail_pipe = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_bwd_persist") {
+#ifndef DG_MEASURE
+        if (atoi(value) <= 0) return fail(DG_E_INVALID, "tail_bwd_persist = 0 (the per-band backward kernel) needs the measurement build");
+#endif
+        h->tail_bwd_persist = atoi(value);
+        return DG_OK;
+    }
+    if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
+        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune") {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        const double v = atof(value);
+        if (k == "jobs.slack") h->job_slack = v;
+        else if (k == "jobs.slots0") h->job_slots_per_cu[0][0] = (int)v > 0 ? (int)v : 1;
+        else if (k == "jobs.slots1") h->job_slots_per_cu[1][0] = (int)v > 0 ? (int)v : 1;
+        else if (k == "jobs.min_level") h->job_min_level = (int)v;
+        else if (k == "jobs.tune") h->job_tune = v != 0.0;
+        else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
+        else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
+        drop_job_lists(h);
+        return DG_OK;
+    }
+    // ---- measurement options: the kernels behind them exist only in the -DDG_MEASURE build of the library
+    if (k == "tail_trace" || k == "tail_fwd16" || k == "tail_bwd_bands" || k == "tail_prio" || k == "tail_dbg" || k == "job_trace") {
+#ifdef DG_MEASURE
     if (k == "tail_trace") {     // read back with dg_debug_read("tail_trace") (int64 pairs viewed as floats)
         HIP_TRY(hipSetDevice(h->device));
         if (atoi(value)) {
@@ -1233,14 +1296,6 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
             (void)hipFree(h->d_tail_trace);
             h->d_tail_trace = nullptr;
         }
-        return DG_OK;
-    }
-    if (k == "tail_pipe") {
-        h->tail_pipe = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_bwd_persist") {
-        h->tail_bwd_persist = atoi(value);
         return DG_OK;
     }
     if (k == "tail_fwd16") {
@@ -1261,27 +1316,16 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->tail_dbg = atoi(value);
         return DG_OK;
     }
-    if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
-        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune") {
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        const double v = atof(value);
-        if (k == "jobs.slack") h->job_slack = v;
-        else if (k == "jobs.slots0") h->job_slots_per_cu[0][0] = (int)v > 0 ? (int)v : 1;
-        else if (k == "jobs.slots1") h->job_slots_per_cu[1][0] = (int)v > 0 ? (int)v : 1;
-        else if (k == "jobs.min_level") h->job_min_level = (int)v;
-        else if (k == "jobs.tune") h->job_tune = v != 0.0;
-        else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
-        else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
-        drop_job_lists(h);
-        return DG_OK;
-    }
     if (k == "job_trace") {      // value = op name ("F2"); read back with dg_debug_read("job_trace") (int64 viewed as floats)
         HIP_TRY(hipSetDevice(h->device));
         if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)kJobTraceCap * 4 * sizeof(long long)));
         HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)kJobTraceCap * 4 * sizeof(long long)));
         h->job_trace_op = value;
         return DG_OK;
+    }
+#else
+        return fail(DG_E_INVALID, "option '%s' needs the measurement build of the library (libdefensegan_hip_measure.so, -DDG_MEASURE)", key);
+#endif
     }
     if (k == "nsplit") {
         const int v = atoi(value);

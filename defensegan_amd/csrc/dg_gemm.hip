@@ -51,8 +51,10 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+#ifdef DG_MEASURE
     long long tr0 = 0;
     if (g.trace) tr0 = wall_clock64();
+#endif
 
     const int s_cnt = jb.pos_count;
     const unsigned magic = jb.magic;
@@ -250,12 +252,14 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     for (int c = 0; c + 1 < nchunks; ++c) chunk_body(c, std::false_type());
     if (nchunks > 0) chunk_body(nchunks - 1, std::true_type());
 
+#ifdef DG_MEASURE
     if (g.trace && tid == 0) {
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         long long* t = g.trace + (long long)blockIdx.x * 4;
         t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
     }
+#endif
     // ---- epilogue: each 32x32 accumulator tile is transposed through this wave's 4 KB slice of the stage the last chunk
     // did NOT use, so that a lane owns 4 consecutive channels of one row: b128 stores (and b128 gate loads).
     float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);

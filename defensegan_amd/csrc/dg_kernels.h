@@ -22,6 +22,18 @@ struct PerDeviceOnce {
 };
 
 
+// Measurement scaffolding (in-kernel phase traces, phase-removal switches, wave-priority hooks, the superseded tail
+// formulations kept as cross-checks) is compiled only with -DDG_MEASURE, into a SECOND library
+// (lib/libdefensegan_hip_measure.so, same sources): the product library's hot kernels carry none of it -- not in their
+// argument blocks either (a switched-off hook changed the register allocation of a GEMM instantiation).
+#ifdef DG_MEASURE
+#define DG_DBG(a) ((a).dbg)
+#define DG_TRACE_PTR(a) ((a).trace)
+#else
+#define DG_DBG(a) 0
+#define DG_TRACE_PTR(a) (static_cast<long long*>(nullptr))
+#endif
+
 enum EpiMode : int {
     EPI_STORE = 0,       // out = acc
     EPI_BIAS = 1,        // out = acc + bias[col]
@@ -53,9 +65,11 @@ struct GemmArgs {
     int mode;                // EpiMode
     int n_jobs;
     int min_level;           // smallest shape code among the jobs (0 = the list holds full tiles)
+#ifdef DG_MEASURE
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
+#endif
 };
-// family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (128x64 / 64x64)
+// family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (256x64 / 128x64 / 64x64)
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
 int gemm_lds_bytes(int family, int min_level);
 
@@ -72,9 +86,11 @@ struct MnistTailArgs {
     int R;
     int C;               // net_dim (64)
     int do_backward;
+    int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
+#ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
     long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr
-    int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
+#endif
 };
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail_mfma.hip
 
@@ -82,7 +98,7 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail
 struct CelebaTailArgs {
     float* h5;           // [N,32,32,C] in: Generator.5 output (no nonlinearity); out: da5
     const float* F6;     // [5,5,3,C]
-    const float* F6p;    // forward filter fragments in MFMA fragment order [3][C/8][64][4] (see dg_tail_mfma.hip)
+    const float* F6p;    // forward filter fragments in MFMA fragment order: 16x16x4 tiles per filter row kh (dg_engine.cpp)
     const float* b6;     // [3]
     const float* x;      // [B,64,64,3]
     float* loss_part;    // [N, 8] per-band partial sums of squared error
@@ -92,16 +108,18 @@ struct CelebaTailArgs {
     int R;
     int C;
     int do_backward;
+    int bwd_persist;     // backward tail: workgroups of the persistent pipelined kernel (> 0)
+#ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 = skip the gather phase, 2 = skip the GEMM phase
-    int bwd_bands;       // backward MFMA tail: 4-input-row bands per workgroup (1, 2 or 4)
-    int fwd16;           // forward MFMA tail: 1 = 16x16x4 kh-aligned formulation (F6p = its pack), 0 = 32x32x2
-    long long* trace;    // optional per-workgroup phase cycle totals [grid][8] (persistent backward tail), or nullptr
-    int bwd_persist;     // backward MFMA tail: > 0 = persistent pipelined kernel with this many workgroups
+    int bwd_bands;       // bwd_persist == 0: per-band backward kernel, 4-input-row bands per workgroup (1, 2 or 4)
+    int fwd16;           // forward tail: 1 = 16x16x4 kh-aligned formulation (F6p = its pack), 0 = 32x32x2 (F6p = the 32-wide pack)
+    long long* trace;    // optional per-workgroup phase cycle totals [grid][8], or nullptr
     int prio;            // wave priority per workgroup slot (see wg_priority); 0 = all equal
+#endif
 };
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // dg_tail_mfma.hip
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s);
-void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s);
+void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, int P, hipStream_t s);   // loss = sum(parts) / P
 
 // ---- small kernels ----------------------------------------------------------------------------
 // m = momentum*m + sum_s part[n][s][:];  z -= lr*m     (ApplyMomentum, gan.py:389-391)

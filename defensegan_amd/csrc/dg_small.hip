@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void celeba_loss_finish_kernel(const float* __
     loss[n] = s * inv_p;
 }
 
-void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, hipStream_t s) {
+void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, int P, hipStream_t s) {
     hipLaunchKernelGGL(celeba_loss_finish_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, s, loss_part, loss, n_rows,
-                       nparts, 1.0f / 12288.0f);
+                       nparts, 1.0f / (float)P);
 }
 
 }  // namespace dg

@@ -79,6 +79,7 @@ __device__ __forceinline__ void tail_load_fwd_weights(const float* __restrict__ 
     }
 }
 
+#ifdef DG_MEASURE
 // Same fragments from the FRAGMENT-ORDER pack built once at weight-load time (dg_engine.cpp, pack_tail_fragments):
 // Wp[((t*C/8 + kk)*64 + lane)*4 + e] -- one fully coalesced 1 KB line run per load instead of 32 partial lines.
 template <int C>
@@ -87,6 +88,8 @@ __device__ __forceinline__ void tail_load_fwd_weights_packed(const float* __rest
     for (int kk = 0; kk < C / 8; ++kk)
         w[0][kk] = *reinterpret_cast<const f32x4*>(Wp + (((long long)t * (C / 8) + kk) * 64 + lane) * 4);
 }
+
+#endif  // DG_MEASURE
 
 // ---- backward GEMM of one 32-position tile ---------------------------------------------------------------------
 // sg: zero-bordered da_out image in LDS, element (row, col, co) at (row*GWP + col)*COUT + co; the tile's position
@@ -264,10 +267,10 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
             }
         };
         store_mask(a0, q0);
-        if (a.dbg != 2) tail_fwd_compute<C, 1>(a0, wave * 32, w, sP, MN_NKP, 0, lane);
+        if (DG_DBG(a) != 2) tail_fwd_compute<C, 1>(a0, wave * 32, w, sP, MN_NKP, 0, lane);
         if (second) {
             store_mask(a1, q1);
-            if (a.dbg != 2) tail_fwd_compute<C, 1>(a1, wave * 32 + 128, w, sP, MN_NKP, 0, lane);
+            if (DG_DBG(a) != 2) tail_fwd_compute<C, 1>(a1, wave * 32 + 128, w, sP, MN_NKP, 0, lane);
         }
     }
     __syncthreads();
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
     const float bias = a.b5[0];
     const float gscale = 2.0f / 784.0f;
     float sq = 0.f;
-    for (int p = tid; p < (a.dbg == 1 ? 0 : 784); p += 256) {
+    for (int p = tid; p < (DG_DBG(a) == 1 ? 0 : 784); p += 256) {
         const int i = p / 28, j = p - i * 28;
         const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
         float s = 0.f;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
     // ---- backward GEMM + ReluGrad (mask bits from LDS), in place over h3 ---------------------------------------------
     BwdWeights<C, 1, MN_GWP> bw;
     bw.load(a.F5, lane);
-    for (int mt = wave; mt < (a.dbg == 3 ? 0 : 7); mt += 4) {
+    for (int mt = wave; mt < (DG_DBG(a) == 3 ? 0 : 7); mt += 4) {
         const int q = mt * 32 + frow;
         const bool valid = q < 196;
         const int qq = valid ? q : 0;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
             fwd(0, A);
         }
         __syncthreads();
-        const bool tr = a.trace != nullptr && wave == 0;
+        const bool tr = DG_TRACE_PTR(a) != nullptr && wave == 0;
         long long ph[5] = {0, 0, 0, 0, 0};
         const long long tb = tr ? (long long)__builtin_readcyclecounter() : 0, wb = tr ? (long long)wall_clock64() : 0;
         for (int t = 0; t <= n_my; ++t) {
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
             }
         }
         if (tr && lane == 0 && blockIdx.x < 2048) {
-            long long* o = a.trace + (long long)blockIdx.x * 16;
+            long long* o = DG_TRACE_PTR(a) + (long long)blockIdx.x * 16;
             for (int i = 0; i < 5; ++i) o[i] = ph[i];
             o[5] = n_my > 4 ? n_my - 4 : 0;
             o[6] = (long long)__builtin_readcyclecounter() - tb;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
         load_x(0, xv0);
         __syncthreads();
         __syncthreads();
-        const bool tr = a.trace != nullptr && wave == 8;
+        const bool tr = DG_TRACE_PTR(a) != nullptr && wave == 8;
         long long gph[2] = {0, 0};
         auto step = [&](int t, float (&xc)[4], float (&xn)[4]) {
             long long c0 = 0, c1 = 0;
@@ -608,7 +611,7 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
             if (t + 1 <= n_my) step(t + 1, xv1, xv0);
         }
         if (tr && lane == 0 && blockIdx.x < 2048) {
-            long long* o = a.trace + (long long)blockIdx.x * 16;
+            long long* o = DG_TRACE_PTR(a) + (long long)blockIdx.x * 16;
             o[8] = gph[0];
             o[9] = gph[1];
         }
@@ -635,6 +638,7 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
 constexpr int CE_NKP = 99;       // 75 kappa columns padded to 96 (+3: gather reads are <= 2-way bank conflicted)
 constexpr int CE_GWP = 68;       // da6 image pitch (cols are image index + 1, 67 used)
 
+#ifdef DG_MEASURE   // the 32x32x2 formulation, superseded by celeba_tail_fwd16_kernel: kept as a cross-check (option tail_fwd16 = 0)
 // One workgroup per (latent row, band of 8 output rows); 6 waves, wave w owns local input row w (4 + 2 halo).
 // Measured alternatives (profiles/r01 notes): fragment-shaped global loads of H (slower than the LDS-DMA staging
 // below), a persistent variant with register prefetch of the next band (slower: both resident workgroups run in
@@ -650,7 +654,7 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
     const int b = n / a.R;
     const float* hrow = a.h5 + (long long)n * (1024 * C);
     const int oh_lo = 4 * band - 1;                              // local input row lr <-> oh_lo + lr
-    if (a.dbg != 2) {
+    if (DG_DBG(a) != 2) {
         const int oh = oh_lo + wave;
         const bool in_img = oh >= 0 && oh < 32;
         // The row's 32 positions x C floats are one contiguous 8 KB (C = 64) run: stage it with full-line LDS-DMA into
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
     float* yrow = a.y ? a.y + (long long)n * 12288 : nullptr;
     const float gscale = 2.0f / 12288.0f;
     float sq = 0.f;
-    if (a.dbg != 1) {
+    if (DG_DBG(a) != 1) {
         float sum[4], xv[4];
         int oidx[4];
 #pragma unroll
@@ -749,6 +753,8 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
     __syncthreads();
     if (tid == 0) a.loss_part[(long long)n * 8 + band] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) + (sred[4] + sred[5]);
 }
+
+#endif  // DG_MEASURE
 
 // ---- forward tail, second formulation: v_mfma_f32_16x16x4_f32 with kh-aligned kappa tiles ------------------------------
 // The 75 filter columns are regrouped per filter row kh: tile kh holds kappa' = kw*3 + co (15 columns, padded to 16).
@@ -794,11 +800,13 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     float* sP = reinterpret_cast<float*>(smem);                // [20][32][17], aliases the staging area
     constexpr int MAINF = (6 * ROWB > CE16_UNITS * CE16_UNIT * 4 ? 6 * ROWB : CE16_UNITS * CE16_UNIT * 4) / 4;
     float* sred = sP + MAINF;
+#ifdef DG_MEASURE
     wg_priority(a.prio);
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x >> 3, band = blockIdx.x & 7;
-    const bool tr = TRACE && a.trace != nullptr && wave == 0 && blockIdx.x >= 3072 && blockIdx.x < 6144;
+    const bool tr = TRACE && DG_TRACE_PTR(a) != nullptr && wave == 0 && blockIdx.x >= 3072 && blockIdx.x < 6144;
     long long tc[TRACE ? 9 : 1];
     auto mark = [&](int i) { if constexpr (TRACE) { if (tr) tc[i] = (long long)__builtin_readcyclecounter(); } };
     mark(0);
@@ -833,7 +841,7 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     constexpr int NI = 32 * CH / 64;                            // DMA instructions per row
     char* stA = smem + (wave < 2 ? wave : wave == 2 ? 2 : 4) * ROWB;
     char* stB = smem + (wave == 2 ? 3 : 5) * ROWB;
-    if (a.dbg != 2 && a.dbg != 4) {
+    if (DG_DBG(a) != 2 && DG_DBG(a) != 4) {
         if (inA) {
             const char* src = reinterpret_cast<const char*>(hrow + (long long)ohA * 32 * C);
 #pragma unroll
@@ -892,7 +900,7 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     // ---- GEMM: 5 (row, kh) units per wave, each 2 position tiles x KK*4 MFMAs (two independent accumulation chains);
     // the next unit's filter fragments are in flight while the current one runs -------------------------------------------
     // unit sequence: kh = (wave == 2 ? 1,2,3,4,0 : 0,1,2,3,4); the second row takes over at step nA
-    if (a.dbg != 2) {
+    if (DG_DBG(a) != 2) {
         const int nA = khA_hi - khA_lo;
         auto unit = [&](const f32x4v (&av)[2][KK], const f32x4v (&w)[KK], int lr, int kh) {
             f32x4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -930,7 +938,7 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     float* yrow = a.y ? a.y + (long long)n * 12288 : nullptr;
     const float gscale = 2.0f / 12288.0f;
     float sq = 0.f;
-    if (a.dbg != 1) {
+    if (DG_DBG(a) != 1) {
         // per-pair column terms: offsets ow*17 + kw*3 + co of the <= 3 taps kw = kw0 + 2*aw
         int colofs[3][3];
         float bias[3];
@@ -1009,12 +1017,13 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     if constexpr (TRACE) {
         if (tr && lane == 0) {
             mark(8);
-            long long* o = a.trace + (long long)(blockIdx.x - 3072 + 1024) * 8;     // rows 1024 .. 4095 of the [4096][8] buffer
+            long long* o = DG_TRACE_PTR(a) + (long long)(blockIdx.x - 3072 + 1024) * 8;     // rows 1024 .. 4095 of the [4096][8] buffer
             for (int i = 0; i < 8; ++i) o[i] = tc[i + 1] - tc[i];
         }
     }
 }
 
+#ifdef DG_MEASURE   // the per-band backward kernel, superseded by the persistent one: kept as a cross-check (option tail_bwd_persist = 0)
 // NB consecutive 4-input-row bands per workgroup: the filter fragments (76 registers) and the launch/ramp cost are
 // paid once per NB * 128 positions.
 template <int C, int NB>
@@ -1056,6 +1065,8 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_mfma_kernel(CelebaTailArg
     }
 }
 
+#endif  // DG_MEASURE
+
 // ---- backward tail, persistent and software-pipelined ---------------------------------------------------------------
 // The per-band workgroup above is three serial phases (fetch da6 + filters, 76 MFMAs per wave, 32 row stores) and every
 // workgroup on the chip runs them in lockstep, so the MFMA pipe idles during the other two.  Here a workgroup keeps the
@@ -1070,7 +1081,9 @@ template <int C>
 __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTailArgs a, int n_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sg0 = reinterpret_cast<float*>(smem);                // two images [11][68][3]
+#ifdef DG_MEASURE
     wg_priority(a.prio);
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fh = lane >> 5;
@@ -1112,14 +1125,14 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
     int buf = 0;
     // optional phase timing (wave 0): [0] fetch issue, [1] gather reads + MFMA issue, [2] store issue,
     // [3] wait for the prefetch + park, [4] absolute start (100 MHz), [5] items, [6] cycles, [7] 100 MHz ticks
-    const bool tr = a.trace != nullptr && a.dbg != 8;          // dbg 8: the forward kernel owns the trace buffer
+    const bool tr = DG_TRACE_PTR(a) != nullptr && DG_DBG(a) != 8;          // dbg 8: the forward kernel owns the trace buffer
     long long ph[5] = {0, 0, 0, 0, 0}, t_begin = tr ? (long long)__builtin_readcyclecounter() : 0, nit = 0;
     const long long w_begin = tr ? (long long)wall_clock64() : 0;     // constant 100 MHz counter
     while (item < n_items) {
         long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
         if (tr) t0 = (long long)__builtin_readcyclecounter();
         const int nxt = item + (int)gridDim.x;
-        if (nxt < n_items && a.dbg != 7) fetch(nxt, pf);
+        if (nxt < n_items && DG_DBG(a) != 7) fetch(nxt, pf);
         if (tr) t1 = (long long)__builtin_readcyclecounter();
         const float* sg = sg0 + buf * CEB_IMG;
         const int n = item >> 3, band = item & 7;
@@ -1129,7 +1142,7 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
         if (tr) t2 = (long long)__builtin_readcyclecounter();
         const int oh = 4 * band + wave;
         bool do_store = true;
-        if (a.dbg == 5 || a.dbg == 7) {                            // timing experiments: no stores (7: no fetch either)
+        if (DG_DBG(a) == 5 || DG_DBG(a) == 7) {                            // timing experiments: no stores (7: no fetch either)
             do_store = false;
 #pragma unroll
             for (int u = 0; u < C / 32; ++u)
@@ -1153,7 +1166,7 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
             }
         }
         if (tr) t3 = (long long)__builtin_readcyclecounter();
-        if (nxt < n_items && a.dbg != 7) park(sg0 + (buf ^ 1) * CEB_IMG, pf);
+        if (nxt < n_items && DG_DBG(a) != 7) park(sg0 + (buf ^ 1) * CEB_IMG, pf);
         if (tr) t4 = (long long)__builtin_readcyclecounter();
         __syncthreads();
         if (tr) {
@@ -1164,7 +1177,7 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
         buf ^= 1;
     }
     if (tr && tid == 0 && blockIdx.x < 4096) {
-        long long* o = a.trace + (long long)blockIdx.x * 8;
+        long long* o = DG_TRACE_PTR(a) + (long long)blockIdx.x * 8;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = ph[q];
         o[4] = w_begin;
@@ -1176,26 +1189,35 @@ __global__ __launch_bounds__(256) void celeba_tail_bwd_persist_kernel(CelebaTail
 
 void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
     static PerDeviceOnce attr;
-    const int lds32 = (192 * CE_NKP + 8) * 4;
     const int main16 = 6 * 32 * a.C * 4 > CE16_UNITS * CE16_UNIT * 4 ? 6 * 32 * a.C * 4 : CE16_UNITS * CE16_UNIT * 4;
     const int lds16 = main16 + 32;
     if (attr.need()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
+#ifdef DG_MEASURE
+        const int lds32 = (192 * CE_NKP + 8) * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_mfma_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 64 * 4 + 32);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd16_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 32 * 128 * 4 + 32);
+#endif
     }
-    if (a.fwd16) {
-        if (a.C == 64 && a.trace && a.dbg == 8) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, true>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
-        else if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
-        else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+#ifdef DG_MEASURE
+    if (!a.fwd16) {
+        const int lds32 = (192 * CE_NKP + 8) * 4;
+        if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
+        else hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<128>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
         return;
     }
-    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<64>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
-    else hipLaunchKernelGGL((celeba_tail_fwd_mfma_kernel<128>), dim3(a.n_rows * 8), dim3(384), lds32, s, a);
+    if (a.C == 64 && a.trace && a.dbg == 8) {
+        hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, true>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+        return;
+    }
+#endif
+    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
+    else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
 }
 
+#ifdef DG_MEASURE
 template <int NB>
 static void launch_celeba_tail_bwd_nb(const CelebaTailArgs& a, hipStream_t s) {
     const int lds = (8 * NB + 3) * CE_GWP * 3 * 4;
@@ -1203,23 +1225,27 @@ static void launch_celeba_tail_bwd_nb(const CelebaTailArgs& a, hipStream_t s) {
     if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<64, NB>), dim3(grid), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((celeba_tail_bwd_mfma_kernel<128, NB>), dim3(grid), dim3(256), lds, s, a);
 }
+#endif
 
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
-    if (a.bwd_persist > 0) {
-        const int n_items = a.n_rows * 8;
-        const int grid = n_items < a.bwd_persist ? n_items : a.bwd_persist;
-        const int lds = (2 * CEB_IMG + 4 * 32 * a.C) * 4;
-        static PerDeviceOnce attr;
-        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_bwd_persist_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * CEB_IMG + 4 * 32 * 128) * 4);
-        if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<64>), dim3(grid), dim3(256), lds, s, a, n_items);
-        else hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<128>), dim3(grid), dim3(256), lds, s, a, n_items);
+#ifdef DG_MEASURE
+    if (a.bwd_persist <= 0) {
+        switch (a.bwd_bands) {
+            case 1: launch_celeba_tail_bwd_nb<1>(a, s); break;
+            case 4: launch_celeba_tail_bwd_nb<4>(a, s); break;
+            default: launch_celeba_tail_bwd_nb<2>(a, s); break;
+        }
         return;
     }
-    switch (a.bwd_bands) {
-        case 1: launch_celeba_tail_bwd_nb<1>(a, s); break;
-        case 4: launch_celeba_tail_bwd_nb<4>(a, s); break;
-        default: launch_celeba_tail_bwd_nb<2>(a, s); break;
-    }
+#endif
+    const int n_items = a.n_rows * 8;
+    const int want = a.bwd_persist > 0 ? a.bwd_persist : 512;
+    const int grid = n_items < want ? n_items : want;
+    const int lds = (2 * CEB_IMG + 4 * 32 * a.C) * 4;
+    static PerDeviceOnce attr;
+    if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_bwd_persist_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (2 * CEB_IMG + 4 * 32 * 128) * 4);
+    if (a.C == 64) hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<64>), dim3(grid), dim3(256), lds, s, a, n_items);
+    else hipLaunchKernelGGL((celeba_tail_bwd_persist_kernel<128>), dim3(grid), dim3(256), lds, s, a, n_items);
 }
 
 }  // namespace dg

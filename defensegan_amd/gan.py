@@ -37,7 +37,7 @@ class DefenseGANBase(object):
     _default_attributes = ['dataset_name', 'batch_size', 'use_bn', 'test_batch_size', 'latent_dim',
                            'net_dim', 'rec_iters', 'image_dim', 'rec_rr', 'rec_lr', 'debug']
 
-    def __init__(self, cfg=None, test_mode=False, verbose=False, device=None, **args):
+    def __init__(self, cfg=None, test_mode=False, verbose=False, device=None, measure=False, **args):
         # defaults of DefenseGANBase.__init__ (gan.py:50-68)
         self.dataset_name = None
         self.batch_size = 32
@@ -51,6 +51,9 @@ class DefenseGANBase(object):
         self.rec_rr = 10
         self.rec_lr = 10.0
         self.rec_momentum = 0.7            # hard-coded in the reference (gan.py:390)
+        # "constant": lr == rec_lr throughout = what the reference executes (its decay never fires, gan.py:362-386);
+        # "intended": the x0.1 staircase at ceil(0.8 * rec_iters) its code asks for.  Off by default.
+        self.rec_lr_schedule = args.get("rec_lr_schedule", "constant")
         self.test_mode = test_mode
         self.verbose = verbose
         self.cfg = dict(cfg) if cfg else {}
@@ -79,17 +82,24 @@ class DefenseGANBase(object):
         if test_mode:
             self.test_batch_size = self.batch_size        # gan.py:105
         self._device = device
+        self._measure = bool(measure)       # True: the -DDG_MEASURE build of the library (tools/, cross-check tests)
         self._handle = None
         self._weights: Dict[str, np.ndarray] = {}
         self._default_seed = 11241990                     # whitebox.py:143 / blackbox.py:464
         self._calls = 0
 
     # ------------------------------------------------------------------ engine plumbing
+    def _lib(self):
+        return _native.load(self._measure)
+
+    def _check(self, rc):
+        self._check(rc, self._lib())
+
     def _ensure_handle(self):
         if self._handle is not None:
             return self._handle
         torch = _torch()
-        lib = _native.load()
+        lib = self._lib()
         if not torch.cuda.is_available():
             raise _native.NativeError("no GPU visible: the projection engine has no CPU fallback")
         dev = self._device
@@ -101,23 +111,24 @@ class DefenseGANBase(object):
             dev = dev.index if dev.index is not None else torch.cuda.current_device()
         self._device = int(dev)
         h = C.c_void_p()
-        _native.check(lib.dg_create(self._arch.arch_id, int(self.latent_dim), int(self.net_dim),
+        self._check(lib.dg_create(self._arch.arch_id, int(self.latent_dim), int(self.net_dim),
                                     1 if self.use_bn else 0, self._device, C.byref(h)))
         self._handle = h
         for k, v in self._weights.items():
             self._push_weight(k, v)
+        self._lr_schedule_set = "constant"
         return h
 
     def _push_weight(self, name: str, arr: np.ndarray):
-        lib = _native.load()
+        lib = self._lib()
         a = np.ascontiguousarray(arr, dtype=np.float32)
         shape = (C.c_int64 * a.ndim)(*a.shape)
-        _native.check(lib.dg_set_weights(self._handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape,
+        self._check(lib.dg_set_weights(self._handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape,
                                          a.ndim, 0))
 
     def close(self):
         if self._handle is not None:
-            _native.load().dg_destroy(self._handle)
+            self._lib().dg_destroy(self._handle)
             self._handle = None
 
     def __del__(self):
@@ -231,7 +242,7 @@ class DefenseGANBase(object):
         if not self.initialized:
             raise _native.NativeError("generator weights not loaded (load_generator / set_weights)")
         torch = _torch()
-        lib = _native.load()
+        lib = self._lib()
         was_numpy = isinstance(images, np.ndarray)
         x = self._to_device(images)
         H, W, Cc = self._arch.image_dim
@@ -244,6 +255,9 @@ class DefenseGANBase(object):
             raise ValueError("got %d images for batch_size=%d" % (B, batch_size))
         R, L = int(self.rec_rr), int(self.rec_iters)
         n_rows = B * R
+        if self.rec_lr_schedule != self._lr_schedule_set:
+            self._check(lib.dg_set_option(self._handle, b"lr_schedule", str(self.rec_lr_schedule).encode()))
+            self._lr_schedule_set = self.rec_lr_schedule
         z0 = None
         if z_init_val is not None:
             z0 = self._to_device(z_init_val)
@@ -259,7 +273,7 @@ class DefenseGANBase(object):
         zout = torch.empty(n_rows, int(self.latent_dim), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         with torch.cuda.device(dev):
-            _native.check(lib.dg_reconstruct(
+            self._check(lib.dg_reconstruct(
                 self._handle, x.data_ptr(), z0.data_ptr() if z0 is not None else None,
                 int(seed) & 0xFFFFFFFFFFFFFFFF, int(first_row), B, R, L, float(self.rec_lr), float(self.rec_momentum),
                 rec.data_ptr(), idx.data_ptr(), loss.data_ptr(), zout.data_ptr(), stream))
@@ -282,7 +296,7 @@ class DefenseGANBase(object):
         dev = torch.device("cuda", self._device)
         B = int(batch_size or self.test_batch_size)
         with torch.cuda.device(dev):
-            _native.check(_native.load().dg_prepare(self._handle, B, int(self.rec_rr),
+            self._check(self._lib().dg_prepare(self._handle, B, int(self.rec_rr),
                                                     torch.cuda.current_stream(dev).cuda_stream))
 
     def reconstruct_dataset(self, splits, checkpoint_dir, batch_size=None, max_num=-1, test_again=False, seed=None):
@@ -347,14 +361,14 @@ class DefenseGANBase(object):
         """G(z): generator_fn(z, is_training=False) (gan.py:399)."""
         self._ensure_handle()
         torch = _torch()
-        lib = _native.load()
+        lib = self._lib()
         was_numpy = isinstance(z, np.ndarray)
         zz = self._to_device(z)
         N = int(zz.shape[0])
         H, W, Cc = self._arch.image_dim
         y = torch.empty(N, H, W, Cc, dtype=torch.float32, device=zz.device)
         with torch.cuda.device(zz.device):
-            _native.check(lib.dg_generate(self._handle, zz.data_ptr(), N, y.data_ptr(),
+            self._check(lib.dg_generate(self._handle, zz.data_ptr(), N, y.data_ptr(),
                                           torch.cuda.current_stream(zz.device).cuda_stream))
         return y.cpu().numpy() if was_numpy else y
 
@@ -363,7 +377,7 @@ class DefenseGANBase(object):
         for images [B,...] and z [B*R, latent] (gan.py:409-417)."""
         self._ensure_handle()
         torch = _torch()
-        lib = _native.load()
+        lib = self._lib()
         was_numpy = isinstance(images, np.ndarray)
         x = self._to_device(images)
         zz = self._to_device(z)
@@ -376,7 +390,7 @@ class DefenseGANBase(object):
         loss = torch.empty(B * R, dtype=torch.float32, device=x.device)
         dz = torch.empty_like(zz)
         with torch.cuda.device(x.device):
-            _native.check(lib.dg_loss_grad(self._handle, x.data_ptr(), zz.data_ptr(), B, R, y.data_ptr(),
+            self._check(lib.dg_loss_grad(self._handle, x.data_ptr(), zz.data_ptr(), B, R, y.data_ptr(),
                                            loss.data_ptr(), dz.data_ptr(),
                                            torch.cuda.current_stream(x.device).cuda_stream))
         if was_numpy:
@@ -386,11 +400,11 @@ class DefenseGANBase(object):
     def init_latents(self, n_rows, seed=0, first_row=0, std=None):
         self._ensure_handle()
         torch = _torch()
-        lib = _native.load()
+        lib = self._lib()
         dev = torch.device("cuda", self._device)
         z = torch.empty(int(n_rows), int(self.latent_dim), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _native.check(lib.dg_init_latents(self._handle, z.data_ptr(), int(n_rows), int(seed), int(first_row),
+            self._check(lib.dg_init_latents(self._handle, z.data_ptr(), int(n_rows), int(seed), int(first_row),
                                               float(std) if std else 0.0,
                                               torch.cuda.current_stream(dev).cuda_stream))
         return z
@@ -398,20 +412,20 @@ class DefenseGANBase(object):
     # ------------------------------------------------------------------ measurement hooks
     def set_option(self, key: str, value) -> None:
         self._ensure_handle()
-        _native.check(_native.load().dg_set_option(self._handle, key.encode(), str(value).encode()))
+        self._check(self._lib().dg_set_option(self._handle, key.encode(), str(value).encode()))
 
     def profile_enable(self, stride: int) -> None:
         self._ensure_handle()
-        _native.check(_native.load().dg_profile_enable(self._handle, int(stride)))
+        self._check(self._lib().dg_profile_enable(self._handle, int(stride)))
 
     def profile_reset(self) -> None:
         self._ensure_handle()
-        _native.check(_native.load().dg_profile_reset(self._handle))
+        self._check(self._lib().dg_profile_reset(self._handle))
 
     def profile_read(self):
         """[{name, launches, ms, flops}] per kernel family since the last reset."""
         self._ensure_handle()
-        lib = _native.load()
+        lib = self._lib()
         n = lib.dg_profile_count(self._handle)
         out = []
         for i in range(max(n, 0)):
@@ -419,7 +433,7 @@ class DefenseGANBase(object):
             launches = C.c_int64()
             ms = C.c_double()
             fl = C.c_double()
-            _native.check(lib.dg_profile_read(self._handle, i, name, 64, C.byref(launches), C.byref(ms), C.byref(fl)))
+            self._check(lib.dg_profile_read(self._handle, i, name, 64, C.byref(launches), C.byref(ms), C.byref(fl)))
             out.append({"name": name.value.decode(), "launches": launches.value, "ms": ms.value, "flops": fl.value})
         return out
 
@@ -429,9 +443,9 @@ class DefenseGANBase(object):
         dev = torch.device("cuda", self._device)
         torch.cuda.synchronize(dev)
         t = torch.empty(int(n), dtype=torch.float32, device=dev)
-        got = _native.load().dg_debug_read(self._handle, what.encode(), t.data_ptr(), int(n))
+        got = self._lib().dg_debug_read(self._handle, what.encode(), t.data_ptr(), int(n))
         if got < 0:
-            _native.check(int(got))
+            self._check(int(got))
         return t[:got]
 
 

@@ -147,12 +147,16 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "jobs.slack"       > 0 fixes the cutting threshold of the job lists (dg_plan.h build_jobs; 1e30 = whole tiles only)
  *   "jobs.min_level"   >= 0 forces every list to start cut to halves (1) / quarters (2)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
+ *   "lr_schedule"      "constant" (default): lr == rec_lr at every step, which is what the reference executes -- the step variable
+ *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,
+ *                      tf.train.exponential_decay(rec_lr, k, ceil(0.8 * rec_iters), 0.1, staircase=True) (base_model.py:186-192)
  *   "nsplit"           split-K factor of the Linear backward (default 16)
  *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
- *   "tail_fwd16"       CelebA forward tail: 1 = 16x16x4 kh-aligned (default), 0 = 32x32x2
- *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel (0 = per-band kernel, "tail_bwd_bands")
- *   "tail_trace", "tail_dbg", "job_trace"   measurement experiments (tools/)
+ *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel
+ * Only in the measurement build of the library (same sources with -DDG_MEASURE -> libdefensegan_hip_measure.so; the product
+ * library refuses them): "tail_fwd16" = 0 (32x32x2 CelebA forward tail), "tail_bwd_persist" = 0 + "tail_bwd_bands" (per-band
+ * backward tail), "tail_trace", "tail_dbg", "tail_prio", "job_trace" (in-kernel phase traces and phase-removal switches, tools/)
  * Every job-list / launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py): GEMM tiles are only
  * ever cut along M and N, never along K; "nsplit" and "tail_fwd16" change a summation order (agreement to rounding).
  */

@@ -217,8 +217,13 @@ def generator_backward(p: Dict[str, np.ndarray], cache, dy: np.ndarray, arch: st
 # --------------------------------------------------------------------------------------------
 def reconstruct(p: Dict[str, np.ndarray], x: np.ndarray, z0: np.ndarray, R: int, L: int,
                 lr: float = 10.0, momentum: float = 0.7, arch: str = "mnist",
-                use_bn: bool = False, dtype=np.float32, trace: bool = False):
+                use_bn: bool = False, dtype=np.float32, trace: bool = False, lr_schedule: str = "constant"):
     """DefenseGANBase.reconstruct (gan.py:333-449).
+
+    lr_schedule: "constant" = what the reference EXECUTES: the decay's step variable `rec_iter_const` is never advanced
+    (gan.py:362-386, 416-417), so exponential_decay always sees step 0 and lr == rec_lr.  "intended" = what the code asks
+    for (gan.py:380-386 -> base_model.py:186-192): tf.train.exponential_decay(rec_lr, step, ceil(0.8 * rec_iters), 0.1,
+    staircase=True) with step = the loop counter, i.e. iteration k uses rec_lr * 0.1 ** floor(k / ceil(0.8 * L)).
 
     x  [B,H,W,C]; z0 [B*R, latent] with row j = b*R + r (gan.py:348-359).
     Schedule (gan.py:409-437): for k in 0..L-1: y_k = G(z_k), loss_k, then the momentum update
@@ -236,6 +241,9 @@ def reconstruct(p: Dict[str, np.ndarray], x: np.ndarray, z0: np.ndarray, R: int,
     z = z0.astype(dtype).copy()
     m = np.zeros_like(z)                                # momentum slot, zero-initialised
     lr_t, mom_t = dt(lr), dt(momentum)
+    if lr_schedule not in ("constant", "intended"):
+        raise ValueError("lr_schedule must be 'constant' or 'intended'")
+    decay_iter = int(np.ceil(L * 0.8)) if L > 0 else 1
     zs: List[np.ndarray] = []
     losses: List[np.ndarray] = []
     steps = max(L, 1)
@@ -251,7 +259,8 @@ def reconstruct(p: Dict[str, np.ndarray], x: np.ndarray, z0: np.ndarray, R: int,
         dy = (dt(2.0) / dt(P)) * d                               # d(sum_j mean_pix)/dy
         g = generator_backward(p, cache, dy, arch, use_bn)
         m = mom_t * m + g                                        # ApplyMomentum (non-Nesterov)
-        z = z - lr_t * m
+        lr_k = lr_t if lr_schedule == "constant" else dt(np.float32(lr) * np.float32(0.1) ** np.float32(k // decay_iter))
+        z = z - lr_k * m
     idx = np.empty(B, np.int32)
     for b in range(B):
         idx[b] = int(np.argmin(loss[b * R:(b + 1) * R]))        # first minimum

@@ -73,17 +73,23 @@ class TorchGenerator:
 
 def reconstruct(params, x: np.ndarray, z0: np.ndarray, R: int, L: int, lr: float = 10.0,
                 momentum: float = 0.7, arch: str = "mnist", use_bn: bool = False,
-                dtype=torch.float32, gen: TorchGenerator = None):
-    """Same contract as defensegan_oracle.reconstruct (gan.py:333-449)."""
+                dtype=torch.float32, gen: TorchGenerator = None, loss_at=None):
+    """Same contract as defensegan_oracle.reconstruct (gan.py:333-449).
+
+    loss_at: optional horizons L' <= L; the result then also holds "loss_at" = {L': image_rec_loss of every restart as a run
+    with rec_iters = L' would return it} (the loss of forward k = L' - 1 does not depend on what follows it)."""
     g = gen or TorchGenerator(params, arch, use_bn, dtype)
     xt = torch.from_numpy(np.ascontiguousarray(x)).to(dtype).repeat_interleave(R, dim=0)
     z = torch.from_numpy(np.ascontiguousarray(z0)).to(dtype).clone()
     m = torch.zeros_like(z)
     steps = max(L, 1)
+    at = {}
     for k in range(steps):
         z.requires_grad_(True)
         y = g.forward(z)
         loss_rows = ((y - xt) ** 2).flatten(1).mean(dim=1)      # reduce_mean over H,W,C
+        if loss_at and (k + 1) in loss_at:
+            at[k + 1] = loss_rows.detach().numpy().copy()
         if k == steps - 1:
             z = z.detach()
             break
@@ -96,5 +102,8 @@ def reconstruct(params, x: np.ndarray, z0: np.ndarray, R: int, L: int, lr: float
     idx = loss.view(B, R).argmin(dim=1)                          # first minimum
     rows = torch.arange(B) * R + idx
     y = y.detach()
-    return {"rec": y[rows].numpy().reshape(x.shape), "idx": idx.numpy().astype(np.int32),
-            "loss": loss.numpy(), "z": z.numpy(), "y": y.numpy()}
+    out = {"rec": y[rows].numpy().reshape(x.shape), "idx": idx.numpy().astype(np.int32),
+           "loss": loss.numpy(), "z": z.numpy(), "y": y.numpy()}
+    if loss_at:
+        out["loss_at"] = at
+    return out

@@ -24,6 +24,30 @@ def test_library_loads_and_exports_everything():
     assert lib.dg_version() == _native.ABI_VERSION
 
 
+def test_measurement_build_is_a_separate_library_with_the_same_abi():
+    """Same sources with -DDG_MEASURE (traces, phase-removal switches, superseded cross-check kernels): its own file, never
+    the one the product path loads; same symbols."""
+    lib, mlib = _native.load(), _native.load(measure=True)
+    assert _native.MEASURE_LIB_PATH != _native.LIB_PATH and mlib is not lib
+    for name in declared_symbols():
+        assert getattr(mlib, name) is not None
+    assert mlib.dg_version() == _native.ABI_VERSION
+
+
+def test_product_library_holds_no_measurement_kernels():
+    """The kernels the verdict called dead-by-default must be absent from the product library's code objects and present
+    in the measurement build."""
+    def blob(path):
+        with open(path, "rb") as f:
+            return f.read()
+    prod, meas = blob(_native.LIB_PATH), blob(_native.MEASURE_LIB_PATH)
+    for sym in (b"27celeba_tail_fwd_mfma_kernelILi", b"27celeba_tail_bwd_mfma_kernelILi", b"celeba_tail_fwd16_kernelILi64ELb1E"):   # mangled
+        assert sym not in prod, sym
+        assert sym in meas, sym
+    for sym in (b"celeba_tail_fwd16_kernel", b"celeba_tail_bwd_persist_kernel", b"mnist_tail_pipe_kernel", b"gemm_batched_kernel"):
+        assert sym in prod, sym
+
+
 def test_no_gpu_calls_fail_cleanly():
     import ctypes as C
     import torch

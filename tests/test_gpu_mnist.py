@@ -219,3 +219,29 @@ def test_cfg5_shard_shape_and_eval_harness():
                                                  first_image=first_image)
     assert n == B and roc[1].shape == (B,) and roc[2].shape == (B,)
     assert 0 <= correct <= B and np.isfinite(roc[2]).all() and (roc[2] >= 0).all()
+
+
+def test_intended_lr_schedule_flag_matches_the_oracle_and_is_off_by_default():
+    """lr == rec_lr throughout is what the reference executes and the default here; the optional
+    rec_lr_schedule = "intended" applies the x0.1 staircase at ceil(0.8 * rec_iters) its code asks for (gan.py:380-386,
+    base_model.py:186-192) -- both against the float64 oracle, L = 10 (the decayed step is update 8)."""
+    from oracle import defensegan_oracle as O
+    B, R, L = 6, 3, 10
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.1, rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, "mnist", B, seed=71)
+    z0 = synth.make_z(B * R, 128, seed=72)
+    assert gan.rec_lr_schedule == "constant"
+    out_c = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    gan.rec_lr_schedule = "intended"
+    out_i = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    gan.rec_lr_schedule = "constant"
+    again = gan.reconstruct(x, z_init_val=z0, return_details=True)
+    assert np.array_equal(again["z"], out_c["z"]) and not np.array_equal(out_i["z"], out_c["z"])
+    for out, sched in ((out_c, "constant"), (out_i, "intended")):
+        ref = O.reconstruct(p, x, z0, R, L, lr=10.0, momentum=0.7, arch="mnist", dtype=np.float64, lr_schedule=sched)
+        np.testing.assert_allclose(out["z"], ref["z"], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(out["loss"], ref["loss"], rtol=5e-4)
+        assert (out["idx"] == ref["idx"]).all()
+    gan.rec_lr_schedule = "cosine"
+    with pytest.raises(Exception, match="lr_schedule"):
+        gan.reconstruct(x, z_init_val=z0)

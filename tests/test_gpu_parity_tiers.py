@@ -63,32 +63,12 @@ def test_config0_reference_cpu_case_vs_float64_oracle():
         assert (out["idx"] == ref["idx"]).all() and (out["idx"] == 0).all()
 
 
-def _stats(v):
-    return np.array([v.mean(), np.percentile(v, 50), np.percentile(v, 90)])
+# horizons (rec_iters) at which the selected restart is compared: the float64 top-2 gaps shrink and the float32 spread grows
+# with the horizon, so the comparison is decidable early and (for CelebA at lr = 10) undecidable at L = 200
+HORIZONS = (5, 10, 20, 50)
 
 
-def _paired_permutation_p(a, b, rs):
-    """P(mean|a| - mean|b| >= observed) when each image's two deviations are exchangeable (one-sided, paired): exact for
-    <= 12 images, 20 000 random label swaps otherwise."""
-    a, b = np.abs(a), np.abs(b)
-    obs = a.mean() - b.mean()
-    n = len(a)
-    if n <= 12:
-        swaps = ((np.arange(1 << n)[:, None] >> np.arange(n)) & 1).astype(bool)
-    else:
-        swaps = rs.rand(20000, n) < 0.5
-    d = np.where(swaps, b - a, a - b).mean(axis=1)
-    return float((d >= obs - 1e-18).mean())
-
-
-def _bootstrap_se(stat, bdev, b64, rs, n_boot=2000):
-    """Standard error of stat(bdev) - stat(b64) over resampled images (pairs kept together)."""
-    n = len(b64)
-    idx = rs.randint(0, n, size=(n_boot, n))
-    return float(np.std([stat(bdev[i]) - stat(b64[i]) for i in idx]))
-
-
-@pytest.mark.parametrize("workload,nb", [("mnist", 48), ("celeba", 8)])
+@pytest.mark.parametrize("workload,nb", [("mnist", 48), ("celeba", 32)])
 def test_distributional_tier_on_the_bench_inputs(workload, nb):
     """The workload bench.py times (BASELINE configs[1] / configs[3]: B = 256 / 128, R = 10, L = 200, lr = 10, adversarial
     inputs).  torch-float32, torch-float64 and the device run the same first ``nb`` images of that batch from the same z0.
@@ -96,17 +76,16 @@ def test_distributional_tier_on_the_bench_inputs(workload, nb):
     What float32 rounding alone does to this loop is seen in d32 = best-restart loss (torch-f32) - (torch-f64), per image;
     the device's deviations are ddev = best(device) - best(f64).  The regime is chaotic (most so for CelebA at lr = 10): any
     change of summation order -- another float32 implementation, or this one with a different K split -- moves individual
-    images by as much as d32 itself, so the comparison is statistical:
+    images by as much as d32 itself, so the comparison is statistical (tests.helpers.distributional_tier: SIZE, BIAS,
+    SELECTION on the decidable images).
 
-    * SIZE: |ddev| is not significantly larger than |d32| (paired permutation test on mean|.|, one-sided, p >= 0.005), and
-      never more than 2.5 x in the mean;
-    * BIAS: mean / p50 / p90 of the device's best-restart loss equal float64's within the fp32-vs-fp64 spread: the larger of
-      twice torch-f32's own deviation of that statistic and three bootstrap standard errors of the device-minus-float64
-      difference (images resampled);
-    * SELECTION: the selected restart equals float64's wherever the float64 top-2 gap exceeds twice that image's per-restart
-      spread (and torch-f32 agrees)."""
+    The argmin of gan.py:438-445 is additionally checked at the shorter horizons rec_iters = 5 / 10 / 20 / 50 at the SAME
+    lr = 10 (one torch run yields the losses of every horizon): wherever the float64 top-2 gap exceeds twice the float32
+    spread the device must select float64's restart, and at the best horizon at least a quarter of the images must be
+    decidable -- for CelebA, where no image is decidable at L = 200, this is what keeps the selection check from being vacuous."""
     import bench
     from oracle import torch_ref as T
+    from tests.helpers import decidable, distributional_tier
     arch, wseed, gain, B, R, L = bench.WORKLOADS[workload]
     a = archs.make_arch(arch)
     gan, p = make_gan(arch, wseed=wseed, gain=gain, bias_range=0.0, rec_rr=R, rec_iters=L, rec_lr=10.0)
@@ -119,36 +98,32 @@ def test_distributional_tier_on_the_bench_inputs(workload, nb):
     dev = out["loss"][:nb * R].cpu().numpy().reshape(nb, R)
     idx = out["idx"][:nb].cpu().numpy()
     torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch=arch)
+    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch=arch, loss_at=HORIZONS)
     t64 = T.reconstruct(p, xs.astype(np.float64), zs.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch=arch,
-                        dtype=torch.float64)
+                        dtype=torch.float64, loss_at=HORIZONS)
     l32, l64 = t32["loss"].reshape(nb, R).astype(np.float64), t64["loss"].reshape(nb, R)
-    b32, b64, bdev = l32.min(axis=1), l64.min(axis=1), dev.min(axis=1).astype(np.float64)
-    d32, ddev = b32 - b64, bdev - b64
-    rs = np.random.RandomState(0)
-    stat_fns = (np.mean, lambda v: np.percentile(v, 50), lambda v: np.percentile(v, 90))
-    s32, s64, sdev = _stats(b32), _stats(b64), _stats(bdev)
-    se = np.array([_bootstrap_se(f, bdev, b64, rs) for f in stat_fns])
-    floor = 1e-6 * b64.mean()
-    tol = np.maximum(np.maximum(2.0 * np.abs(s32 - s64), 3.0 * se), floor)
-    p_size = _paired_permutation_p(ddev, d32, rs)
-    msg = ("best-restart loss  [mean, p50, p90]\n  f64 %s\n  f32 %s\n  dev %s\n  tol %s\n  mean|d32| %.3e  mean|ddev| %.3e  "
-           "permutation p %.4f" % (s64, s32, sdev, tol, np.abs(d32).mean(), np.abs(ddev).mean(), p_size))
+    msg, decided = distributional_tier(l32, l64, dev, idx)
     print(msg)
-    assert np.isfinite(dev).all()
-    # size of the deviations
-    assert np.abs(ddev).mean() <= 2.5 * np.abs(d32).mean() + floor, msg
-    assert p_size >= 0.005 or np.abs(ddev).mean() <= np.abs(d32).mean() + floor, msg
-    # bias of the distribution's statistics
-    assert (np.abs(sdev - s64) <= tol).all(), msg
-    # selection: decidable images only
-    srt = np.sort(l64, axis=1)
-    spread_b = np.abs(l32 - l64).max(axis=1)
-    decided = ((srt[:, 1] - srt[:, 0]) > 2.0 * spread_b) & (t32["idx"] == t64["idx"])
-    print("decidable images: %d of %d" % (decided.sum(), nb))
-    assert (idx[decided] == t64["idx"][decided]).all(), (idx, t64["idx"], decided)
-    if workload == "mnist":
-        assert decided.mean() >= 0.25                                   # the comparison is not vacuous
     # the reported reconstruction error of the BASELINE metric ("recon MSE"): MSE(rec, x) of the selected restart
     mse_dev = ((out["rec"][:nb] - x[:nb]) ** 2).flatten(1).mean(dim=1).cpu().numpy()
-    np.testing.assert_allclose(mse_dev, bdev, rtol=2e-4)
+    np.testing.assert_allclose(mse_dev, dev.min(axis=1), rtol=2e-4)
+    # ---- selection at the shorter horizons, same lr
+    fracs = {L: float(decided.mean())}
+    for Lh in HORIZONS:
+        gan.rec_iters = Lh
+        o = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
+        ld = o["loss"].cpu().numpy().reshape(nb, R).astype(np.float64)
+        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        dec = decidable(h32, h64)
+        fracs[Lh] = float(dec.mean())
+        sel = o["idx"].cpu().numpy()
+        assert (sel[dec] == h64.argmin(axis=1)[dec]).all(), (Lh, sel, h64.argmin(axis=1), dec)
+        # the per-restart losses themselves: 9 rows in 10 within 3 x the float32 restatement's own largest distance from
+        # float64 at this horizon (plus float32 resolution) -- tight while rounding is not yet amplified, loose in the chaos
+        tol = 3.0 * np.abs(h32 - h64).max() + 4e-6 * np.abs(h64)
+        assert (np.abs(ld - h64) <= tol).mean() >= 0.9, (Lh, np.abs(ld - h64).max(), np.abs(h32 - h64).max())
+    gan.rec_iters = L
+    print("decidable fraction by horizon: %s" % fracs)
+    assert max(fracs.values()) >= 0.25, fracs                           # the selection comparison is not vacuous
+    if workload == "mnist":
+        assert fracs[L] >= 0.25, fracs

@@ -20,10 +20,19 @@ def _oracle():
     return O
 
 
-def _make(arch, net_dim=64, latent_dim=128, gain=2.0, R=2, L=3, seed=1234):
+# options whose kernels exist only in the measurement build of the library (-DDG_MEASURE, lib/libdefensegan_hip_measure.so):
+# the superseded tail formulations, kept as cross-checks of the product kernels
+MEASURE_ONLY = ("tail_fwd16", "tail_bwd_bands", "tail_dbg", "tail_prio", "tail_trace", "job_trace")
+
+
+def _needs_measure(opts):
+    return any(k in MEASURE_ONLY for k in opts) or str(opts.get("tail_bwd_persist", 1)) == "0"
+
+
+def _make(arch, net_dim=64, latent_dim=128, gain=2.0, R=2, L=3, seed=1234, measure=False):
     from defensegan_amd.gan import dataset_gan_dict
     gan = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": latent_dim, "NET_DIM": net_dim}, test_mode=True,
-                                 rec_rr=R, rec_iters=L, rec_lr=10.0)
+                                 rec_rr=R, rec_iters=L, rec_lr=10.0, measure=measure)
     p = synth.make_weights(arch, seed=seed, gain=gain, bias_range=0.1, latent_dim=latent_dim, net_dim=net_dim)
     assert gan.set_weights(p) == []
     return gan, p
@@ -90,12 +99,24 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
     ref = _run(gan, x, z0)
     assert np.isfinite(ref["loss"]).all()
     for opts in BITWISE[arch]:
-        g2, _ = _make(arch, R=R, L=3)
+        g2, _ = _make(arch, R=R, L=3, measure=_needs_measure(opts))
         for k, v in opts.items():
             g2.set_option(k, v)
         got = _run(g2, x, z0)
         for k in ("rec", "idx", "loss", "z"):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+def test_measurement_options_are_refused_by_the_product_library():
+    """The product library carries no measurement kernels: their options fail loudly instead of being ignored."""
+    from defensegan_amd import _native
+    gan, _ = _make("celeba", R=2, L=1)
+    for k, v in (("tail_fwd16", 0), ("tail_bwd_persist", 0), ("tail_dbg", 1), ("tail_trace", 1), ("job_trace", "F2")):
+        with pytest.raises(_native.NativeError, match="measurement build"):
+            gan.set_option(k, v)
+    gan.set_option("tail_bwd_persist", 300)          # the product kernel's own knob stays
+    gm, _ = _make("celeba", R=2, L=1, measure=True)
+    gm.set_option("tail_fwd16", 0)
 
 
 @pytest.mark.parametrize("arch,opts", [("celeba", {"tail_fwd16": 0}), ("mnist", {"nsplit": 4}), ("mnist", {"nsplit": 8})])
@@ -108,7 +129,7 @@ def test_reordered_formulations_agree_to_rounding(arch, opts):
     x = np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32)
     z = (rs.standard_normal((B * R, 128)) * 0.15).astype(np.float32)
     y0, l0, g0 = gan.loss_grad(x, z)
-    g2, _ = _make(arch, R=R, L=1)
+    g2, _ = _make(arch, R=R, L=1, measure=_needs_measure(opts))
     for k, v in opts.items():
         g2.set_option(k, v)
     y1, l1, g1 = g2.loss_grad(x, z)

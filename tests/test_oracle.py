@@ -180,3 +180,31 @@ def test_contractive_regime_converges_fp32_vs_fp64():
     assert (o64["loss"] < 0.2 * l0).all()
     np.testing.assert_allclose(o32["loss"], o64["loss"], rtol=2e-3, atol=1e-7)
     assert (o32["idx"] == o64["idx"]).all()
+
+
+def test_intended_lr_schedule_is_the_staircase_the_reference_asks_for_and_off_by_default():
+    """the decay of gan.py:380-386 (exponential_decay(rec_lr, step, ceil(0.8 L), 0.1, staircase), via
+    base_model.py:186-192) never fires in the reference because its step variable is never advanced -- the default
+    ("constant") reproduces that; "intended" applies lr * 0.1 ** floor(k / ceil(0.8 L)) at iteration k."""
+    from defensegan_amd import synth
+    p = synth.make_weights("mnist", seed=3, gain=2.0, bias_range=0.05)
+    rs = np.random.RandomState(0)
+    x, _ = O.generator_forward(p, (rs.standard_normal((2, 128)) * 0.09).astype(np.float32), "mnist")
+    z0 = synth.make_z(4, 128, seed=1)
+    L = 10                                           # decay_iter = 8: updates 0..7 at lr, update 8 at lr / 10
+    a = O.reconstruct(p, x, z0, 2, L, lr=10.0, dtype=np.float64, trace=True)
+    b = O.reconstruct(p, x, z0, 2, L, lr=10.0, dtype=np.float64, trace=True, lr_schedule="intended")
+    d = O.reconstruct(p, x, z0, 2, L, lr=10.0, dtype=np.float64, trace=True, lr_schedule="constant")
+    assert all(np.array_equal(u, v) for u, v in zip(a["z_trace"], d["z_trace"]))          # the default IS constant
+    for k in range(9):
+        assert np.array_equal(a["z_trace"][k], b["z_trace"][k]), k                        # identical up to z_8
+    assert not np.array_equal(a["z_trace"][9], b["z_trace"][9])
+    # z_9 = z_8 - lr_8 * m_9 with the same m_9 in both runs: the step is exactly ten times smaller
+    step_a, step_b = a["z_trace"][9] - a["z_trace"][8], b["z_trace"][9] - b["z_trace"][8]
+    np.testing.assert_allclose(step_b, 0.1 * step_a, rtol=1e-6, atol=1e-12)
+    # short runs never reach the decay: ceil(0.8 * 5) = 4 and the last applied update is k = 3
+    e = O.reconstruct(p, x, z0, 2, 5, lr=10.0, dtype=np.float64)
+    f = O.reconstruct(p, x, z0, 2, 5, lr=10.0, dtype=np.float64, lr_schedule="intended")
+    assert np.array_equal(e["rec"], f["rec"])
+    with pytest.raises(ValueError):
+        O.reconstruct(p, x, z0, 2, 5, lr_schedule="cosine")

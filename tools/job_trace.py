@@ -21,7 +21,7 @@ for kv in sys.argv[2:]:
     elif k == "B": B = int(v)
     else: opts[k] = v
 a = archs.make_arch(arch)
-gan = dataset_gan_dict[arch](cfg={"USE_BN": False}, test_mode=True, rec_rr=R, rec_iters=3, device=0)
+gan = dataset_gan_dict[arch](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=R, rec_iters=3, device=0)
 gan.set_weights(synth.make_weights(arch, seed=1234, gain=2.0))
 for k, v in opts.items():
     gan.set_option(k, v)

@@ -32,7 +32,7 @@ if args.zero:
     params = {k: np.zeros_like(v) for k, v in params.items()}
 configs = args.set or [""]
 for cfg in configs:
-    gan = dataset_gan_dict[args.arch](cfg={"USE_BN": False}, test_mode=True, rec_rr=args.R, rec_iters=args.L, device=0)
+    gan = dataset_gan_dict[args.arch](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=args.R, rec_iters=args.L, device=0)
     gan.set_weights(params)
     for kv in [c for c in cfg.split(",") if c]:
         k, v = kv.split("=")

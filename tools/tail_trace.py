@@ -14,7 +14,7 @@ from defensegan_amd.gan import dataset_gan_dict
 
 B, R, L = 128, 10, 4
 a = archs.make_arch("celeba")
-gan = dataset_gan_dict["celeba"](cfg={"USE_BN": False}, test_mode=True, rec_rr=R, rec_iters=L, device=0)
+gan = dataset_gan_dict["celeba"](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=R, rec_iters=L, device=0)
 gan.set_weights(synth.make_weights("celeba", seed=1234, gain=2.0))
 FWD = "fwd" in sys.argv[1:]
 for kv in sys.argv[1:]:

@@ -13,7 +13,7 @@ from defensegan_amd.gan import dataset_gan_dict
 
 B, R, L = 256, 10, 4
 a = archs.make_arch("mnist")
-gan = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True, rec_rr=R, rec_iters=L, device=0)
+gan = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=R, rec_iters=L, device=0)
 gan.set_weights(synth.make_weights("mnist", seed=1234, gain=2.0))
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
