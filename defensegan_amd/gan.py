@@ -93,7 +93,7 @@ class DefenseGANBase(object):
         return _native.load(self._measure)
 
     def _check(self, rc):
-        self._check(rc, self._lib())
+        _native.check(rc, self._lib())
 
     def _ensure_handle(self):
         if self._handle is not None:

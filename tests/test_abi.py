@@ -60,3 +60,21 @@ def test_no_gpu_calls_fail_cleanly():
     assert lib.dg_last_error()
     assert lib.dg_create(7, 128, 64, 0, 0, C.byref(h)) == -1          # DG_E_INVALID before any HIP call
     assert lib.dg_create(0, 100, 64, 0, 0, C.byref(h)) == -1
+
+
+def test_python_mirror_reports_native_errors_without_a_gpu():
+    """The host class turns a non-zero status into NativeError carrying the library's message (and raises, never falls back,
+    when no GPU is visible)."""
+    import numpy as np
+    import pytest
+    import torch
+    from defensegan_amd.gan import MnistDefenseGAN
+    g = MnistDefenseGAN(cfg={"USE_BN": False}, test_mode=True)
+    with pytest.raises(_native.NativeError, match="defensegan_hip error -1"):
+        g._check(-1)
+    g._check(0)
+    if not torch.cuda.is_available():
+        with pytest.raises(_native.NativeError, match="no CPU fallback"):
+            g.reconstruct(np.zeros((1, 28, 28, 1), np.float32))
+        with pytest.raises(_native.NativeError, match="no CPU fallback"):
+            g.prepare(4)
