@@ -188,22 +188,27 @@ def _free_port():
 
 
 def resolve_ranks(n_gpus, env, device_count):
-    """(world, rank, local_rank, relaunch) for `--gpus n_gpus` under the environment `env` on a node with `device_count`
-    GPUs.  relaunch = True: this process must re-exec itself under torch.distributed.run (N > 1 asked for, no launcher
-    present).  Raises SystemExit with a message -- never a silent 1-GPU run -- when the request cannot be honoured."""
+    """(world, rank, device index, relaunch) for `--gpus n_gpus` under the environment `env` on a node where this process sees
+    `device_count` GPUs.  relaunch = True: this process must re-exec itself under torch.distributed.run (N > 1 asked for, no
+    launcher present).  Raises SystemExit with a message -- never a silent 1-GPU run -- when the request cannot be honoured."""
     if n_gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1 (got %d)" % n_gpus)
-    if device_count < n_gpus:
-        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node; refusing to report a %d-GPU "
-                         "number from fewer devices" % (n_gpus, device_count, n_gpus))
     if "WORLD_SIZE" not in env:
+        if device_count < n_gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) are visible on this node; refusing to report a %d-GPU "
+                             "number from fewer devices" % (n_gpus, device_count, n_gpus))
         return (1, 0, 0, False) if n_gpus == 1 else (n_gpus, 0, 0, True)
+    # a launcher started us: it must have started exactly N ranks, and this rank must have a GPU of its own
     world, rank, local_rank = int(env["WORLD_SIZE"]), int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0"))
     if world != n_gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (n_gpus, world))
-    if not (0 <= local_rank < device_count):
-        raise SystemExit("bench.py: LOCAL_RANK=%d but %d GPU(s) are visible" % (local_rank, device_count))
-    return world, rank, local_rank, False
+    if device_count < 1:
+        raise SystemExit("bench.py: --gpus %d: rank %d sees 0 GPU(s) (no GPU visible)" % (n_gpus, rank))
+    if 0 <= local_rank < device_count:
+        return world, rank, local_rank, False
+    if device_count == 1:
+        return world, rank, 0, False            # the launcher narrowed this rank's visibility to its own GPU
+    raise SystemExit("bench.py: LOCAL_RANK=%d but %d GPU(s) are visible to this rank" % (local_rank, device_count))
 
 
 def main():

@@ -146,7 +146,11 @@ struct dg_handle {
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
     // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
     int lr_intended = 0;
-    int two_streams = 0;   // number of concurrent row groups; measured +0.4 .. +1.3 % at 2560 rows, -10 % at 500: off (also keeps kernel timings comparable with rocprof)
+    // number of concurrent row groups (each on its own stream).  Off: measured again in round 3 on one box with 2 .. 8 groups,
+    // tuned and whole-tile job lists (profiles/r03_exp_stream_groups.txt): MNIST 2560 rows 966.7 vs 966.6 img/s with 2 groups,
+    // slower with 3+ (a queue only gets workgroup slots as the other's kernel retires them, so two MFMA-bound kernels do not
+    // overlap beyond their launch ends, and the half-size launches are less efficient); CelebA +0.9 %; 500 rows -13 %.
+    int two_streams = 0;
     int two_stream_min_rows = 1024;
     static constexpr int kMaxGroups = 8;
     hipStream_t side_stream[kMaxGroups - 1] = {};

@@ -49,34 +49,50 @@ void launch_momentum_update(float* z, float* m, const float* part, int nsplit, i
 }
 
 // ---- selection: first argmin over the R restarts of each image, then gather (gan.py:438-449) ------
-__global__ __launch_bounds__(64) void select_kernel(const float* __restrict__ loss, const float* __restrict__ y,
-                                                    int R, int P, float* __restrict__ out_rec,
-                                                    int32_t* __restrict__ out_idx) {
+// One 256-thread workgroup per image: wave 0 finds the first minimum (wave shuffles), everybody copies the selected row
+// (b128 when both rows are 16-byte aligned: P % 4 == 0 and aligned bases; dwords otherwise).
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ loss, const float* __restrict__ y,
+                                                     int R, int P, float* __restrict__ out_rec,
+                                                     int32_t* __restrict__ out_idx, int vec4) {
+    __shared__ int s_bi;
     const int b = blockIdx.x;
-    const int lane = threadIdx.x;
-    float best = __builtin_inff();
-    int bi = 0x7fffffff;
-    for (int r = lane; r < R; r += 64) {
-        const float v = loss[(long long)b * R + r];
-        // strict "<" keeps the first minimum; a NaN loss never wins (all-NaN rows select restart 0)
-        if (v < best || (v == best && r < bi)) { best = v; bi = r; }
-    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 64) {
+        float best = __builtin_inff();
+        int bi = 0x7fffffff;
+        for (int r = lane; r < R; r += 64) {
+            const float v = loss[(long long)b * R + r];
+            // strict "<" keeps the first minimum; a NaN loss never wins (all-NaN rows select restart 0)
+            if (v < best || (v == best && r < bi)) { best = v; bi = r; }
+        }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = __shfl_xor(best, m, 64);
-        const int oi = __shfl_xor(bi, m, 64);
-        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (bi == 0x7fffffff) bi = 0;
+        if (lane == 0) {
+            s_bi = bi;
+            if (out_idx) out_idx[b] = bi;
+        }
     }
-    if (bi == 0x7fffffff) bi = 0;
-    if (lane == 0 && out_idx) out_idx[b] = bi;
-    const float* src = y + ((long long)b * R + bi) * P;
+    __syncthreads();
+    const float* src = y + ((long long)b * R + s_bi) * P;
     float* dst = out_rec + (long long)b * P;
-    for (int i = lane; i < P; i += 64) dst[i] = src[i];
+    if (vec4) {
+        const float4* s4 = reinterpret_cast<const float4*>(src);
+        float4* d4 = reinterpret_cast<float4*>(dst);
+        for (int i = tid; i < (P >> 2); i += 256) d4[i] = s4[i];
+    } else {
+        for (int i = tid; i < P; i += 256) dst[i] = src[i];
+    }
 }
 
 void launch_select(const float* loss, const float* y, int B, int R, int P, float* out_rec, int32_t* out_idx,
                    hipStream_t s) {
-    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(64), 0, s, loss, y, R, P, out_rec, out_idx);
+    const int vec4 = (P % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out_rec)) % 16 == 0);
+    hipLaunchKernelGGL(select_kernel, dim3(B), dim3(256), 0, s, loss, y, R, P, out_rec, out_idx, vec4);
 }
 
 // ---- latent init: z ~ N(0, std^2), Philox4x32-10 + Box-Muller ------------------------------------

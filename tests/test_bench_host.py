@@ -128,8 +128,10 @@ def test_gpus_n_never_degrades_to_a_one_gpu_run():
     assert r(8, {}, 8) == (8, 0, 0, True)                                   # no launcher: relaunch with 8 ranks
     assert r(2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, 8) == (2, 1, 1, False)
     assert r(1, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, 1) == (1, 0, 0, False)   # DG_BENCH_FORCE_DIST runs
+    # a launcher that narrows each rank's visibility to its own GPU (one device visible, LOCAL_RANK beyond it): device 0
+    assert r(8, {"WORLD_SIZE": "8", "RANK": "5", "LOCAL_RANK": "5"}, 1) == (8, 5, 0, False)
     for n, env, ndev in [(8, {}, 1), (2, {}, 0), (8, {"WORLD_SIZE": "1"}, 8), (2, {"WORLD_SIZE": "4"}, 8),
-                         (2, {"WORLD_SIZE": "2", "LOCAL_RANK": "1"}, 1), (0, {}, 1),
+                         (2, {"WORLD_SIZE": "2", "LOCAL_RANK": "1"}, 0), (0, {}, 1),
                          (2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "5"}, 4)]:
         with pytest.raises(SystemExit) as e:
             r(n, env, ndev)

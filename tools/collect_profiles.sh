@@ -28,5 +28,10 @@ F=$(find $OUT/pmc -name "celeba_fetch*results.db" | head -1); Wd=$(find $OUT/pmc
 python tools/pmc_traffic.py celeba $F $Wd $BUILD > $OUT/pmc_traffic_celeba.json 2>> $OUT/pmc_traffic.err
 python tools/pmc_summary.py $(find $OUT/pmc -name "*_sq*results.db") > $OUT/pmc_sq.txt 2> $OUT/pmc_sq.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/ \;
+# per-LAYER rows (one symbol serves several layers; candidate-list launches folded out): tools/kernel_trace_by_layer.py
+for W in mnist celeba mnist_use_bn; do
+  T=$(find $OUT/stats -name "${W}_kernel_trace.csv" | head -1)
+  [ -n "$T" ] && python tools/kernel_trace_by_layer.py $T $OUT/bench_${W}_under_rocprof.json > $OUT/${W}_kernel_stats_by_layer.csv 2>> $OUT/by_layer.err
+done
 find $OUT -name "*.db" -delete
 ls -la $OUT

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Per-LAYER kernel statistics from a rocprofv3 --kernel-trace csv.
+
+rocprofv3 --stats aggregates by kernel SYMBOL, and one symbol serves several layers here (gemm_batched_kernel<0, 2, 1> is both
+the Linear forward, 33 us, and Generator.2's forward, 277 us), so a symbol's average means nothing; the launches that time
+candidate job lists (dg_prepare) are mixed into every symbol's Calls as well.  A layer's launches all have the same
+(symbol, grid size, LDS size) -- its job list -- so grouping by that triple separates the layers; groups with fewer than
+`min_calls` launches (the candidate lists that were not kept) are folded into one "other" row per symbol.
+
+    python tools/kernel_trace_by_layer.py <kernel_trace.csv> [bench.json] [min_calls] > per_layer.csv
+
+With the JSON line bench.py printed in the same run, each group is labelled with the layer whose hipEvent average (bench.py's
+"kernels" rows, same symbol) is closest to the group's average.
+"""
+import collections
+import csv
+import json
+import math
+import re
+import sys
+
+
+def short(k):
+    k = k.replace("(anonymous namespace)::", "").replace("dg::", "")
+    return re.sub(r"^void ", "", k.split("(")[0])
+
+
+def main():
+    path = sys.argv[1]
+    rest = sys.argv[2:]
+    layers = []
+    if rest and not rest[0].isdigit():
+        try:
+            with open(rest[0]) as f:
+                layers = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1]).get("kernels", [])
+        except Exception:
+            layers = []
+        rest = rest[1:]
+    min_calls = int(rest[0]) if rest else 64
+
+    def layer_of(name, mean_ns):
+        cands = [k for k in layers if k["kernel"] == name]
+        if not cands:
+            return ""
+        best = min(cands, key=lambda k: abs(k["avg_us"] * 1e3 - mean_ns))
+        return best["name"] if abs(best["avg_us"] * 1e3 - mean_ns) <= 0.25 * mean_ns else ""
+    groups = collections.defaultdict(list)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            grid = int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"]))
+            key = (short(row["Kernel_Name"]), grid, int(row["LDS_Block_Size"]))
+            groups[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    folded = collections.defaultdict(list)
+    rows = []
+    for (name, grid, lds), d in groups.items():
+        if len(d) < min_calls and "gemm_batched_kernel" in name:
+            folded[name].extend(d)
+        else:
+            rows.append((name, grid, lds, d))
+    for name, d in folded.items():
+        rows.append((name + " [candidate job lists, not kept]", 0, 0, d))
+    total = sum(sum(d) for _, _, _, d in rows)
+    w = csv.writer(sys.stdout)
+    w.writerow(["Layer", "Kernel", "Workgroups", "LDS_bytes", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+    for name, grid, lds, d in sorted(rows, key=lambda r: -sum(r[3])):
+        n, s = len(d), sum(d)
+        mean = s / n
+        sd = math.sqrt(sum((x - mean) ** 2 for x in d) / n)
+        w.writerow([layer_of(name, mean) if grid else "", name, grid, lds, n, s, round(mean, 1), round(100.0 * s / total, 2), min(d), max(d), round(sd, 1)])
+
+
+if __name__ == "__main__":
+    main()
