@@ -165,7 +165,7 @@ struct dg_handle {
     std::vector<int64_t> act_row;  // floats per latent row
     double* bn_part = nullptr;     // BN partial sums scratch
     float* g6 = nullptr;           // CelebA: da6 [N, 64*64*3]
-    float* loss_part = nullptr;    // CelebA: [N, 8]
+    float* loss_part = nullptr;    // CelebA: [N, 8 bands, 4 waves] partial sums of squared error
 
     // profiling
     int prof_stride = 0;
@@ -358,7 +358,7 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
     if (h->arch == DG_ARCH_CELEBA64) {
         HIP_TRY(hipMalloc(&h->g6, cap * h->P * sizeof(float)));
-        HIP_TRY(hipMalloc(&h->loss_part, cap * 8 * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->loss_part, cap * 32 * sizeof(float)));
     }
     const int nd = (int)h->dec.size();
     h->act.assign(nd, nullptr);
@@ -731,7 +731,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
 #endif
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
-        t.loss_part = h->loss_part + r0 * 8;
+        t.loss_part = h->loss_part + r0 * 32;
         t.y = want_y ? h->y + r0 * h->P : nullptr;
         t.g6 = h->g6 + r0 * h->P;
         t.n_rows = n_rows;

@@ -101,7 +101,7 @@ struct CelebaTailArgs {
     const float* F6p;    // forward filter fragments in MFMA fragment order: 16x16x4 tiles per filter row kh (dg_engine.cpp)
     const float* b6;     // [3]
     const float* x;      // [B,64,64,3]
-    float* loss_part;    // [N, 8] per-band partial sums of squared error
+    float* loss_part;    // [N, 8 bands, 4 waves] partial sums of squared error (celeba_loss_finish_kernel adds them in a fixed order)
     float* y;            // [N,64,64,3] or nullptr
     float* g6;           // [N,64,64,3] scratch for da6 (needed across band borders)
     int n_rows;

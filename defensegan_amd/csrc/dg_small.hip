@@ -150,13 +150,17 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
                        (unsigned long long)seed, (long long)first_row, std);
 }
 
-// ---- CelebA loss: sum of the per-band partial squared errors of a latent row, / P (gan.py:410-414) ----
+// ---- CelebA loss: sum of the per-(band, wave) partial squared errors of a latent row, / P (gan.py:410-414) ----
+// part [n_rows][nparts bands][4 waves]; fixed order ((w0 + w1) + (w2 + w3)) per band, bands in sequence.
 __global__ __launch_bounds__(256) void celeba_loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss,
                                                                  int n_rows, int nparts, float inv_p) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= n_rows) return;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += part[(long long)n * nparts + k];
+    for (int k = 0; k < nparts; ++k) {
+        const float4 q = *reinterpret_cast<const float4*>(part + ((long long)n * nparts + k) * 4);
+        s += (q.x + q.y) + (q.z + q.w);
+    }
     loss[n] = s * inv_p;
 }
 
