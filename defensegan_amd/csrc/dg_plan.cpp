@@ -268,6 +268,28 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
 
 }  // namespace
 
+void order_for_xcd(std::vector<JobDesc>& jobs, int n_rows, double head_frac, int n_xcd) {
+    if (n_xcd < 2 || n_rows < n_xcd || head_frac <= 0.0) return;
+    size_t head = (size_t)((double)jobs.size() * (head_frac < 1.0 ? head_frac : 1.0));
+    head -= head % (size_t)n_xcd;
+    if (head < (size_t)(2 * n_xcd)) return;
+    std::vector<std::vector<JobDesc>> bucket((size_t)n_xcd);
+    for (size_t i = 0; i < head; ++i) {
+        long long x = (long long)jobs[i].n_first * n_xcd / n_rows;
+        if (x >= n_xcd) x = n_xcd - 1;
+        bucket[(size_t)x].push_back(jobs[i]);
+    }
+    for (auto& b : bucket)          // ascending latent row; jobs of one row keep their (cost) order
+        std::stable_sort(b.begin(), b.end(), [](const JobDesc& a, const JobDesc& c) { return a.n_first < c.n_first; });
+    // slot i of the list goes to XCD i mod n_xcd: deal the buckets out round-robin; a bucket that runs dry (row ranges need not
+    // hold the same number of jobs) is skipped, the longer ones then share its slots
+    std::vector<size_t> at((size_t)n_xcd, 0);
+    size_t out = 0;
+    while (out < head)
+        for (int x = 0; x < n_xcd && out < head; ++x)
+            if (at[(size_t)x] < bucket[(size_t)x].size()) jobs[out++] = bucket[(size_t)x][at[(size_t)x]++];
+}
+
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model) {
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
     for (int i = 0; i < slots; ++i) free_at.push(0.0);

@@ -71,6 +71,15 @@ struct JobModel {
 };
 std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, int slots, double slack,
                                 const JobModel& model = JobModel(), double* predicted_us = nullptr, int min_level = 0);
+// Locality order for the 8 XCDs of an MI355X (each with its own 4 MB L2; the dispatcher hands consecutive workgroups to
+// consecutive XCDs, workgroup i -> XCD i mod n_xcd): the first `head_frac` of a dispatch-ordered list -- the long whole-tile
+// jobs, which in cost order are class-major, i.e. every XCD sweeps the whole batch once per class and re-fetches each input
+// row from the fabric for every class and tap -- is re-arranged so that XCD x receives the jobs of latent rows
+// [x, x + 1) * n_rows / n_xcd in ascending row order, all classes (and column tiles) of a row range next to each other in
+// time: the input rows a resident set of jobs touches then fit the XCD's L2.  The tail of the list (short jobs, cut pieces)
+// keeps its longest-first order, which is what levels the end of the launch.  A pure permutation: results cannot change.
+void order_for_xcd(std::vector<JobDesc>& jobs, int n_rows, double head_frac, int n_xcd = 8);
+
 // Makespan (microseconds) of greedy list scheduling of `jobs` in order on `slots` servers of 1/slots of the chip each.
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model);
 

@@ -95,6 +95,12 @@ int dgp2_make_jobs(void* h, int n_rows, int slots, double alpha) {
     b.jobs = dg::build_jobs(b.plan, n_rows, b.family, slots, alpha, dg::JobModel(), &b.predicted_us);
     return (int)b.jobs.size();
 }
+// re-arranges the list built last (dg_plan.h order_for_xcd) and returns its simulated makespan on `slots` slots
+double dgp2_order_for_xcd(void* h, int n_rows, double head_frac, int n_xcd, int slots) {
+    Batched& b = *static_cast<Batched*>(h);
+    dg::order_for_xcd(b.jobs, n_rows, head_frac, n_xcd);
+    return dg::simulate_jobs(b.plan, b.jobs, b.family, slots, dg::JobModel());
+}
 double dgp2_predicted_us(void* h) { return static_cast<Batched*>(h)->predicted_us; }
 void dgp2_jobs(void* h, int* out) {           // per job: cls, shape, n0, n_first, j_first, m_valid
     const Batched& b = *static_cast<Batched*>(h);
