@@ -134,7 +134,12 @@ struct dg_handle {
     int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};   // resident workgroups per CU by (family, smallest level in the list)
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
-    double job_xcd_head = 0.75;    // > 0: lists longer than the resident slots are also tried in XCD-locality order (dg_plan.h order_for_xcd)
+    // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
+    // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
+    // launch took the same time (465 vs 466 us), fetched the same bytes across the L2/fabric boundary (907 vs 910 MB raw) and
+    // clocked the same: one latent row of that layer's input is 256 KB, so the rows even a row-ordered resident set touches
+    // (~50 per XCD) are three times the 4 MB L2 -- the re-reads of the 25-tap pattern are served by the Infinity Cache either way.
+    double job_xcd_head = 0.0;
     dg::JobModel job_model;
     long long* d_job_trace = nullptr;
     std::string job_trace_op;

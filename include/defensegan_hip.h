@@ -146,7 +146,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      operands and keeps the fastest; 0: the cost model's simulated makespan decides
  *   "jobs.slack"       > 0 fixes the cutting threshold of the job lists (dg_plan.h build_jobs; 1e30 = whole tiles only)
  *   "jobs.min_level"   >= 0 forces every list to start cut to halves (1) / quarters (2)
- *   "jobs.xcd_head"    fraction (default 0.75, 0 = off) of a list that is ALSO offered to the timing in XCD-locality order: every
+ *   "jobs.xcd_head"    fraction (default 0 = off; measured, no gain) of a list that is ALSO offered to the timing in XCD-locality order: every
  *                      XCD gets the jobs of one contiguous range of latent rows, all tap classes of a row range next to each other
  *                      in time, so that their shared input rows stay in that XCD's L2 (a permutation of the list)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
