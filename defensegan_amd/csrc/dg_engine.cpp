@@ -103,7 +103,7 @@ struct ProfEntry {
 };
 struct ProfPending {
     int entry;
-    hipEvent_t e0, e1;
+    int e0, e1;          // indices into dg_handle::prof_events
 };
 
 }  // namespace
@@ -131,7 +131,10 @@ struct dg_handle {
     // reference's default batch) 756.6 vs 777.9, CelebA 305.2 vs 305.2.
     int nsplit = 16;
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
-    int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};   // resident workgroups per CU by (family, smallest level in the list)
+    // Resident workgroups per CU by (family, smallest level in the list) = what LDS admits: 160 KB / (64 | 80, 48, 32 KB of
+    // gemm_lds_bytes) = 2, 3, 5.  The kernel's __launch_bounds__(256, 2 / 3 / 4) is the MINIMUM occupancy the register allocator
+    // must leave room for, not a cap: the level-2 instantiations use 62-68 VGPRs, so registers admit 7 and LDS decides (5).
+    int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
@@ -179,6 +182,12 @@ struct dg_handle {
     std::vector<ProfEntry> prof;
     std::vector<ProfPending> pending;
     std::map<std::string, int> prof_index;
+    // Markers of the profiled launches, in stream order.  Consecutive launches SHARE the marker between them (the end of one
+    // is the start of the next), so the durations of a profiled step add up to its wall time exactly -- a separate event pair
+    // per launch counted every dispatch boundary twice (round 2: the breakdown summed 1.3 % above the timed step).
+    std::vector<hipEvent_t> prof_events;
+    hipStream_t prof_chain_stream = nullptr;
+    int prof_chain_last = -1;      // index of the marker recorded after the previous profiled launch, -1 = chain broken
 };
 
 namespace {
@@ -191,24 +200,35 @@ int prof_slot(dg_handle* h, const std::string& name) {
     return (int)h->prof.size() - 1;
 }
 
-struct ProfScope {   // brackets one launch with events when sampling is on for this iteration
+struct ProfScope {   // brackets one launch with stream markers when sampling is on for this iteration
     dg_handle* h;
     hipStream_t s;
     bool on;
     int entry = -1;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int i0 = -1;
     double flops;
+    static int new_marker(dg_handle* h, hipStream_t s) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        if (hipEventRecord(e, s) != hipSuccess) { (void)hipEventDestroy(e); return -1; }
+        h->prof_events.push_back(e);
+        return (int)h->prof_events.size() - 1;
+    }
     ProfScope(dg_handle* h_, hipStream_t s_, bool on_, const std::string& name, double flops_)
         : h(h_), s(s_), on(on_), flops(flops_) {
         if (!on) return;
         entry = prof_slot(h, name);
-        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
-        (void)hipEventRecord(e0, s);
+        // the marker after the previous profiled launch on this stream is this launch's start
+        i0 = (h->prof_chain_last >= 0 && h->prof_chain_stream == s) ? h->prof_chain_last : new_marker(h, s);
+        if (i0 < 0) on = false;
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(e1, s);
-        h->pending.push_back(ProfPending{entry, e0, e1});
+        const int i1 = new_marker(h, s);
+        h->prof_chain_stream = s;
+        h->prof_chain_last = i1;
+        if (i1 < 0) return;
+        h->pending.push_back(ProfPending{entry, i0, i1});
         h->prof[entry].flops += flops;
     }
 };
@@ -216,14 +236,16 @@ struct ProfScope {   // brackets one launch with events when sampling is on for 
 void prof_collect(dg_handle* h) {
     for (auto& p : h->pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+        if (hipEventSynchronize(h->prof_events[p.e1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, h->prof_events[p.e0], h->prof_events[p.e1]) == hipSuccess) {
             h->prof[p.entry].ms += ms;
             h->prof[p.entry].launches += 1;
         }
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
     }
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    h->prof_events.clear();
     h->pending.clear();
+    h->prof_chain_last = -1;
 }
 
 // A failed launch (bad configuration, LDS limit, ...) is reported by the layer it happened in, not at the end of the call.
@@ -1109,6 +1131,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     hipStream_t s = (hipStream_t)stream;
     rc = prepare_call(h, B, R, s);          // a no-op (no allocation, no wait) once this shape has been prepared
     if (rc) return rc;
+    h->prof_chain_last = -1;                // profile markers never span two calls (copies and the latent draw sit between)
     const size_t zbytes = (size_t)n_rows * h->latent * sizeof(float);
     if (z0) HIP_TRY(hipMemcpyAsync(h->z, z0, zbytes, hipMemcpyDeviceToDevice, s));
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
