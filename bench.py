@@ -16,7 +16,9 @@ images (FGSM eps = 0.3 inputs from the bare classifier, model A; built untimed),
 in batches, with the single all_gather of (labels, preds, diffs) at the end; images/s = 10 000 / wall ("scaling": "strong").
 
 The timed region carries NO instrumentation.  Per-kernel durations for the roofline leg come from ONE extra, untimed
-step after it, in which every kernel of every GD iteration is bracketed by hipEvents on the launch stream.
+step after it, in which every kernel of every GD iteration sits between two hipEvent markers on the launch stream
+(consecutive launches share the marker between them, so the durations add up to that step's wall time,
+`roofline.profiled_step_ms`; the markers themselves make that step ~2 % longer than a timed one).
 """
 from __future__ import annotations
 
@@ -73,7 +75,7 @@ def traffic_for(workload, kernel, B, R):
     return doc.get(key, {}).get(kernel, {}).get("bytes_per_launch"), "profiles/" + TRAFFIC_FILE
 
 
-TRAFFIC_FILE = "r02_pmc_traffic.json"
+TRAFFIC_FILE = "r03_pmc_traffic.json"
 
 
 def make_inputs(gan, a, B, rank=0, first_image=0):
@@ -337,11 +339,15 @@ def main():
 
     # ---- untimed: one more step with every kernel of every GD iteration bracketed by hipEvents (rank 0 reports)
     prof = []
+    profiled_step_ms = None
     if not args.no_profile and not args.strong:
         gan.profile_reset()
         gan.profile_enable(1)
+        torch.cuda.synchronize(dev)
+        tp0 = time.perf_counter()
         step(args.warmup + args.steps)
         torch.cuda.synchronize(dev)
+        profiled_step_ms = (time.perf_counter() - tp0) * 1e3
         gan.profile_enable(0)
         prof = gan.profile_read()
 
@@ -350,6 +356,9 @@ def main():
         flop_img = archs.flop_per_image(a, R, max(L, 1))
         path_tflops = value * flop_img / 1e12 / world           # per GPU
         kernels, roofline = roofline_from_profile(prof, args.workload + ("_bn" if args.use_bn else ""), B, R, path_tflops)
+        # wall time of the ONE untimed step that carried the stream markers: its kernels' durations (consecutive launches share
+        # a marker) add up to it; it is longer than a timed step by what ~8 markers per GD iteration cost (~3 us each)
+        roofline["profiled_step_ms"] = round(profiled_step_ms, 3) if profiled_step_ms is not None else None
         cfgno = 4 if args.strong else {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload]
         if args.strong:
             wl = ("%s whitebox FGSM eps=0.3 (classifier model A, dg_fgsm) evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
