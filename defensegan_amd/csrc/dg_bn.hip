@@ -17,8 +17,7 @@ namespace dg {
 constexpr int BN_MAX_BLOCKS = 1024;  // row blocks of the partial sums (upper bound; bn_part is sized for it)
 constexpr int BN_MIN_ROWS = 32;      // rows per block, at least
 constexpr int BN_COLS = 1024;        // channels per workgroup (256 threads x 4)
-constexpr int BN_FSPLIT = 64;        // finalize: threads per channel
-constexpr int BN_FCH = 256 / BN_FSPLIT;   // finalize: channels per workgroup
+constexpr int BN_FSPLIT = 16;        // finalize: threads per channel
 
 static inline long long bn_rows_per_block(long long rows) {
     const long long r = (rows + BN_MAX_BLOCKS - 1) / BN_MAX_BLOCKS;
@@ -90,16 +89,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 
 // forward: stats[0][c] = mean, stats[1][c] = rstd = 1/sqrt(var + eps)
 // backward: stats[0][c] = mean(dy), stats[1][c] = mean(dy * xhat)
-// BN_FCH channels per workgroup, BN_FSPLIT threads per channel: thread j of a channel adds blocks j, j + BN_FSPLIT, ... (4 loads in
-// flight), the BN_FSPLIT sums are folded in LDS in a fixed order.  (Round 3: 64 threads per channel instead of 16 -- the kernel
-// is a chain of dependent L2 round trips, 16 of them for 1024 blocks at 16 threads per channel: 8.1 us x 6 launches per GD
-// iteration of a USE_BN generator.)
+// 16 channels per workgroup, 16 threads per channel: thread j of a channel adds blocks j, j+16, ... (4 loads in flight), the
+// 16 sums are folded in LDS in a fixed order.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblk, long long rows, int C,
                                                           float* __restrict__ stats, int forward) {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
-    const int cl = tid % BN_FCH, j = tid / BN_FCH;
-    const int c = blockIdx.x * BN_FCH + cl;
+    const int cl = tid & 15, j = tid >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
         int k = j;
@@ -121,7 +118,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     red[0][tid] = s1; red[1][tid] = s2;
     __syncthreads();
     if (j != 0 || c >= C) return;
-    for (int k = 1; k < BN_FSPLIT; ++k) { s1 += red[0][k * BN_FCH + cl]; s2 += red[1][k * BN_FCH + cl]; }
+    for (int k = 1; k < BN_FSPLIT; ++k) { s1 += red[0][k * 16 + cl]; s2 += red[1][k * 16 + cl]; }
     const double m1 = s1 / (double)rows, m2 = s2 / (double)rows;
     if (forward) {
         double var = m2 - m1 * m1;
@@ -185,7 +182,7 @@ static void launch_bn_stats(const float* a, const float* b, const BnArgs& args, 
     const dim3 grid((unsigned)nblk, (unsigned)((args.C + BN_COLS - 1) / BN_COLS));
     if (b) hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
     else hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((args.C + BN_FCH - 1) / BN_FCH), dim3(256), 0, s, args.part, nblk, (long long)args.rows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((args.C + 15) / 16), dim3(256), 0, s, args.part, nblk, (long long)args.rows,
                        args.C, stats, forward);
 }
 
