@@ -151,6 +151,7 @@ struct dg_handle {
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
     int tail_bwd_persist = 512;
+    int tail_fwd_split = 0;        // CelebA forward tail: workgroups of the role-split persistent kernel (0 = celeba_tail_fwd16_kernel)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
@@ -387,7 +388,7 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
     if (h->arch == DG_ARCH_CELEBA64) {
         HIP_TRY(hipMalloc(&h->g6, cap * h->P * sizeof(float)));
-        HIP_TRY(hipMalloc(&h->loss_part, cap * 32 * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->loss_part, cap * 64 * sizeof(float)));
     }
     const int nd = (int)h->dec.size();
     h->act.assign(nd, nullptr);
@@ -769,6 +770,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.F6 = h->F[nd - 1];
         t.F6p = h->tail_pack16;
         t.bwd_persist = h->tail_bwd_persist;
+        t.fwd_split = (last.cin == 64) ? h->tail_fwd_split : 0;
 #ifdef DG_MEASURE
         t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
         t.fwd16 = h->tail_fwd16;
@@ -779,7 +781,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
 #endif
         t.b6 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
-        t.loss_part = h->loss_part + r0 * 32;
+        t.loss_part = h->loss_part + r0 * 64;
         t.y = want_y ? h->y + r0 * h->P : nullptr;
         t.g6 = h->g6 + r0 * h->P;
         t.n_rows = n_rows;
@@ -791,11 +793,11 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
 #ifdef DG_MEASURE
             ProfScope ps(h, s, prof, h->tail_fwd16 ? "T6f@celeba_tail_fwd16_kernel" : "T6f@celeba_tail_fwd_mfma_kernel", 2.0 * macs * n_rows);
 #else
-            ProfScope ps(h, s, prof, "T6f@celeba_tail_fwd16_kernel", 2.0 * macs * n_rows);
+            ProfScope ps(h, s, prof, t.fwd_split > 0 ? "T6f@celeba_tail_fwd_split_kernel" : "T6f@celeba_tail_fwd16_kernel", 2.0 * macs * n_rows);
 #endif
             dg::launch_celeba_tail_fwd_mfma(t, s);
         }
-        if (want_loss) dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, 8, h->P, s);
+        if (want_loss) dg::launch_celeba_loss_finish(t.loss_part, h->loss + r0, n_rows, t.fwd_split > 0 ? 16 : 8, h->P, s);
         if (tail_backward) {
 #ifdef DG_MEASURE
             ProfScope ps(h, s, prof, h->tail_bwd_persist > 0 ? "T6b@celeba_tail_bwd_persist_kernel" : "T6b@celeba_tail_bwd_mfma_kernel", 2.0 * macs * n_rows);
@@ -1313,6 +1315,10 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "tail_pipe") {
         h->tail_pipe = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_fwd_split") {
+        h->tail_fwd_split = atoi(value) > 0 ? atoi(value) : 0;
         return DG_OK;
     }
     if (k == "tail_bwd_persist") {

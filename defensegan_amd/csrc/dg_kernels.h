@@ -101,7 +101,7 @@ struct CelebaTailArgs {
     const float* F6p;    // forward filter fragments in MFMA fragment order: 16x16x4 tiles per filter row kh (dg_engine.cpp)
     const float* b6;     // [3]
     const float* x;      // [B,64,64,3]
-    float* loss_part;    // [N, 8 bands, 4 waves] partial sums of squared error (celeba_loss_finish_kernel adds them in a fixed order)
+    float* loss_part;    // [N, nparts, 4] partial sums of squared error; nparts = 8 bands (fwd16) or 16 half-bands (role-split kernel); celeba_loss_finish_kernel adds them in a fixed order
     float* y;            // [N,64,64,3] or nullptr
     float* g6;           // [N,64,64,3] scratch for da6 (needed across band borders)
     int n_rows;
@@ -109,6 +109,7 @@ struct CelebaTailArgs {
     int C;
     int do_backward;
     int bwd_persist;     // backward tail: workgroups of the persistent pipelined kernel (> 0)
+    int fwd_split;       // forward tail (C = 64): > 0 = role-split persistent kernel on half-bands with this many workgroups; 0 = celeba_tail_fwd16_kernel
 #ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 = skip the gather phase, 2 = skip the GEMM phase
     int bwd_bands;       // bwd_persist == 0: per-band backward kernel, 4-input-row bands per workgroup (1, 2 or 4)

@@ -1024,6 +1024,245 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
     }
 }
 
+// ---- forward tail, third formulation: persistent, ROLE-SPLIT workgroups on half-bands -----------------------------------
+// celeba_tail_fwd16_kernel runs stage -> GEMM -> gather strictly in sequence inside a workgroup and leaves it to three resident
+// workgroups per CU to overlap each other's phases (MFMA pipe 43 % busy).  Here a workgroup is 8 waves with two roles and
+// walks a strided list of items (latent row n, half-band hb = 4 output rows):
+//     waves 0-3 ("M"): stage the item's input rows by LDS-DMA, multiply;   waves 4-7 ("G"): gather + tanh + loss + da6
+// In step s the M waves multiply item s + 1 (results stay in registers) while the G waves gather item s from P; then
+// barrier, the M waves drop their 5 accumulators into P, barrier.  A half-band's 4 output rows i = 4 hb + il need the input rows
+// oh = 2 hb - 1 + lr, lr = 0..3, through 10 (lr, kh) units
+//     lr0: kh 3,4     lr1: kh 1..4     lr2: kh 0..2     lr3: kh 0               (i = 2 oh + kh - 1)
+// = 20 half-units of 16 positions, 5 per M wave: wave w = 2 c + m takes position half m of the rows of class c
+//     c = 0: (lr1; kh 1,2,3,4) + (lr3; kh 0)          c = 1: (lr2; kh 0,1,2) + (lr0; kh 3,4)
+// so every wave stages exactly the two half-rows it multiplies (8 LDS-DMA pieces; no other wave reads them, so no barrier
+// sits between staging and the fragment reads), and its five half-units are five independent accumulation chains.  The
+// filter fragments (all five kh, 20 KB) live in LDS for the workgroup's life: the M waves issue no ordinary load inside the
+// loop, so their vmcnt counts LDS-DMA pieces only and item s + 2's rows are in flight for a whole step (a filter load
+// issued behind a DMA would have to wait for it: VMEM returns in order).  LDS: 32 KB stage + 21.8 KB P + 20 KB filters = 73.3 KB,
+// two workgroups per CU.  G wave g owns output row il = g (its kh terms are wave-uniform), lane l the column j = l with its three
+// channels (12 contiguous bytes per lane for x, y and da6).  Sums keep the order of celeba_tail_fwd16_kernel (kh ascending, kw
+// ascending; one k-ordered MFMA chain per P entry): y and da6 are bit-identical to it.
+constexpr int CES_UNITS = 10;
+constexpr int CES_PBUF = CES_UNITS * CE16_UNIT;          // floats of the P buffer
+// P slot of unit (lr, kh): lr0 -> kh - 3, lr1 -> 1 + kh, lr2 -> 6 + kh, lr3 -> 9
+__device__ __forceinline__ constexpr int ces_slot(int lr, int kh) { return lr == 0 ? kh - 3 : lr == 1 ? 1 + kh : lr == 2 ? 6 + kh : 9; }
+
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are complete, then s_barrier.  Unlike __syncthreads()
+// it does not wait for outstanding global / LDS-DMA traffic (vmcnt), which the M waves keep in flight across steps on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int C>
+__global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTailArgs a, int n_items) {
+    static_assert(C == 64, "position half = 16 positions x 64 channels = one 4 KB run; other widths use celeba_tail_fwd16_kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KK = C / 16, CH = C / 4, ROWB = 32 * C * 4;
+    char* stage = smem;                                               // [4 rows][32 positions][C]
+    float* sP = reinterpret_cast<float*>(smem + 4 * ROWB);            // [CES_UNITS][32][17]
+    float* sW = sP + CES_PBUF;                                        // filter fragments [5 kh][KK][64 lanes][4] (= the pack's layout)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_my = (n_items - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto item_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+    for (int i = tid; i < 5 * KK * 64; i += 512)
+        reinterpret_cast<f32x4v*>(sW)[i] = reinterpret_cast<const f32x4v*>(a.F6p)[i];
+
+    if (wave < 4) {
+        // ================================================ M role ================================================
+        const int m = wave & 1;
+        const bool cls0 = wave < 2;
+        const int lrA = cls0 ? 1 : 2, lrB = cls0 ? 3 : 0;
+        const int fi = lane & 15, fg = lane >> 4;
+        char* stA = stage + lrA * ROWB + m * 16 * (C * 4);
+        char* stB = stage + lrB * ROWB + m * 16 * (C * 4);
+        auto row_ok = [&](int item, int lr) { const int oh = 2 * (item & 15) - 1 + lr; return oh >= 0 && oh < 32; };
+        auto stage_half = [&](int item, int lr, char* dst) {
+            if (!row_ok(item, lr)) return;
+            const int n = item >> 4, oh = 2 * (item & 15) - 1 + lr;
+            const char* src = reinterpret_cast<const char*>(a.h5 + (long long)n * (1024 * C) + (long long)(oh * 32 + 16 * m) * C);
+#pragma unroll
+            for (int q = 0; q < 16 * CH / 64; ++q) {
+                const int slot = q * 64 + lane;
+                const int pos = slot / CH, c = slot % CH;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                    (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, CE16_DMA_AUX);
+            }
+        };
+        auto read_frags = [&](const char* st, f32x4v (&av)[KK]) {
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+                av[kk] = *reinterpret_cast<const f32x4v*>(st + fi * (C * 4) + (((4 * kk + fg) ^ (fi & (CH - 1))) << 4));
+        };
+        const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4v acc[5];
+        bool okB = false;
+        // five half-units = five independent accumulation chains; chain c multiplies row (c < NA ? A : B) by filter row KH[c]
+        auto compute = [&](int item) {
+            f32x4v avA[KK], avB[KK];
+            okB = row_ok(item, lrB);
+            read_frags(stA, avA);                                      // row A always exists (lr 1, 2)
+            if (okB) read_frags(stB, avB);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (item + (int)gridDim.x < n_items) {                     // the next item's half-rows go out now: a whole step to land
+                stage_half(item + (int)gridDim.x, lrA, stA);
+                stage_half(item + (int)gridDim.x, lrB, stB);
+            }
+#pragma unroll
+            for (int c = 0; c < 5; ++c) acc[c] = z4;
+            auto chains = [&](auto cls_tag) {
+                constexpr bool C0 = decltype(cls_tag)::value;
+                constexpr int NA = C0 ? 4 : 3;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    f32x4v wk[5];
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) {
+                        const int kh = C0 ? (c < 4 ? c + 1 : 0) : c;
+                        wk[c] = *reinterpret_cast<const f32x4v*>(sW + (((kh * KK + kk) * 64 + lane) << 2));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int c = 0; c < 5; ++c) {
+                            if (c < NA) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[kk][e], wk[c][e], acc[c], 0, 0, 0);
+                            else if (okB) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[kk][e], wk[c][e], acc[c], 0, 0, 0);
+                        }
+                }
+            };
+            if (cls0) chains(std::true_type()); else chains(std::false_type());
+        };
+        auto store_p = [&]() {
+#pragma unroll
+            for (int c = 0; c < 5; ++c) {
+                const int slot = cls0 ? (c < 4 ? ces_slot(1, c + 1) : ces_slot(3, 0)) : (c < 3 ? ces_slot(2, c) : ces_slot(0, c));
+                if ((cls0 ? c < 4 : c < 3) || okB) {
+                    float* pu = sP + slot * CE16_UNIT;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pu[(16 * m + 4 * fg + r) * CE16_PITCH + fi] = acc[c][r];
+                }
+            }
+        };
+        // prologue: rows of item 0; every compute(item k) sends item k + 1's rows out as soon as it has read its own
+        stage_half(item_of(0), lrA, stA);
+        stage_half(item_of(0), lrB, stB);
+        lds_barrier();                                               // filter fragments are in LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        compute(item_of(0));
+        store_p();
+        lds_barrier();
+        for (int s = 0; s < n_my; ++s) {
+            const bool more = s + 1 < n_my;
+            if (more) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // item s + 1's half-rows (issued one step ago) have landed
+                compute(item_of(s + 1));
+            }
+            lds_barrier();                                           // the G waves have read P of item s
+            if (more) store_p();
+            lds_barrier();
+        }
+    } else {
+        // ================================================ G role ================================================
+        const int g = wave - 4;                                          // output row il of the half-band
+        const int j = lane;                                              // output column; channels co = 0..2
+        const float gscale = 2.0f / 12288.0f;
+        // column terms: offsets ow * 17 + kw * 3 + co of the <= 3 taps kw = kw0 + 2 aw; a tap that does not exist reads the unit's
+        // zero pad column (kappa' = 15 of position 0: the filter pack's 16th column is zero)
+        int colofs[3][3];
+        float bias[3];
+        {
+            const int kw0 = (j + 1) & 1;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                bias[co] = a.b6[co];
+#pragma unroll
+                for (int aw = 0; aw < 3; ++aw) {
+                    const int kw = kw0 + 2 * aw;
+                    const int ow = (j + 1 - kw) >> 1;
+                    colofs[co][aw] = (kw > 4 || ow < 0 || ow >= 32) ? 15 : ow * CE16_PITCH + kw * 3 + co;
+                }
+            }
+        }
+        // kh terms of row il = g in ascending kh (the order celeba_tail_fwd16_kernel adds them in): P slot and input row lr
+        //   il 0: kh 1 (lr1), 3 (lr0)      il 1: kh 0 (lr2), 2 (lr1), 4 (lr0)      il 2: kh 1 (lr2), 3 (lr1)      il 3: kh 0 (lr3), 2 (lr2), 4 (lr1)
+        const int nt = (g & 1) ? 3 : 2;
+        int tslot[3], tlr[3];
+        if (g == 0) { tslot[0] = ces_slot(1, 1); tlr[0] = 1; tslot[1] = ces_slot(0, 3); tlr[1] = 0; tslot[2] = ces_slot(1, 1); tlr[2] = 1; }
+        else if (g == 1) { tslot[0] = ces_slot(2, 0); tlr[0] = 2; tslot[1] = ces_slot(1, 2); tlr[1] = 1; tslot[2] = ces_slot(0, 4); tlr[2] = 0; }
+        else if (g == 2) { tslot[0] = ces_slot(2, 1); tlr[0] = 2; tslot[1] = ces_slot(1, 3); tlr[1] = 1; tslot[2] = ces_slot(2, 1); tlr[2] = 2; }
+        else { tslot[0] = ces_slot(3, 0); tlr[0] = 3; tslot[1] = ces_slot(2, 2); tlr[1] = 2; tslot[2] = ces_slot(1, 4); tlr[2] = 1; }
+        auto load_x = [&](int item, float (&xv)[3]) {
+            const int n = item >> 4, hb = item & 15;
+            const float* xrow = a.x + (long long)((unsigned)n / (unsigned)a.R) * 12288 + (4 * hb + g) * 192 + 3 * j;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) xv[co] = xrow[co];
+        };
+        auto gather = [&](int item, const float (&xv)[3]) {
+            const int n = item >> 4, hb = item & 15;
+            float tv[3][9];
+            bool use[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int oh = 2 * hb - 1 + tlr[t];
+                use[t] = t < nt && oh >= 0 && oh < 32;                      // wave-uniform
+                // a term that does not exist (third kh of an even row, a row outside the image) re-reads a slot that does and is
+                // not summed: its own slot holds whatever an earlier item left there
+                const float* pu = sP + (use[t] ? tslot[t] : ces_slot(1, 1 + g)) * CE16_UNIT;
+#pragma unroll
+                for (int co = 0; co < 3; ++co)
+#pragma unroll
+                    for (int aw = 0; aw < 3; ++aw) tv[co][t * 3 + aw] = pu[colofs[co][aw]];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+#pragma unroll
+                for (int q = 0; q < 9; ++q) asm volatile("" : "+v"(tv[co][q]));
+            float sq = 0.f;
+            const long long oi = (long long)n * 12288 + (4 * hb + g) * 192 + 3 * j;
+            float yv[3], gv[3];
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    if (!use[t]) continue;
+#pragma unroll
+                    for (int aw = 0; aw < 3; ++aw) sacc += tv[co][t * 3 + aw];
+                }
+                const float v = sacc + bias[co];
+                const float tt = __builtin_amdgcn_exp2f(-2.8853900817779268f * __builtin_fabsf(v));
+                const float y = __builtin_copysignf((1.0f - tt) * __builtin_amdgcn_rcpf(1.0f + tt), v);
+                const float d = y - xv[co];
+                sq = __builtin_fmaf(d, d, sq);
+                yv[co] = y;
+                gv[co] = gscale * d * (1.0f - y * y);
+            }
+#pragma unroll
+            for (int co = 0; co < 3; ++co) a.g6[oi + co] = gv[co];
+            if (a.y) {
+#pragma unroll
+                for (int co = 0; co < 3; ++co) a.y[oi + co] = yv[co];
+            }
+#pragma unroll
+            for (int mm = 32; mm >= 1; mm >>= 1) sq += __shfl_xor(sq, mm, 64);
+            if (lane == 0) a.loss_part[((long long)n * 16 + hb) * 4 + g] = sq;
+        };
+        lds_barrier();
+        lds_barrier();
+        for (int s = 0; s < n_my; ++s) {
+            // x of this item is requested first and used last (after the LDS reads and the tanh): its L2 latency sits under them.
+            // (Requesting it a step ahead does not help: the wait for it is a vmcnt(0), which would then also wait for the
+            // request just issued for the step after.)
+            float xv[3];
+            load_x(item_of(s), xv);
+            gather(item_of(s), xv);
+            lds_barrier();
+            lds_barrier();
+        }
+    }
+}
+
 #ifdef DG_MEASURE   // the per-band backward kernel, superseded by the persistent one: kept as a cross-check (option tail_bwd_persist = 0)
 // NB consecutive 4-input-row bands per workgroup: the filter fragments (76 registers) and the launch/ramp cost are
 // paid once per NB * 128 positions.
@@ -1214,6 +1453,15 @@ void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s) {
         return;
     }
 #endif
+    if (a.C == 64 && a.fwd_split > 0) {
+        const int n_items = a.n_rows * 16;
+        const int grid = n_items < a.fwd_split ? n_items : a.fwd_split;
+        const int lds = 4 * 32 * 64 * 4 + CES_PBUF * 4 + 5 * (64 / 16) * 64 * 16;
+        static PerDeviceOnce attr2;
+        if (attr2.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(celeba_tail_fwd_split_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((celeba_tail_fwd_split_kernel<64>), dim3(grid), dim3(512), lds, s, a, n_items);
+        return;
+    }
     if (a.C == 64) hipLaunchKernelGGL((celeba_tail_fwd16_kernel<64, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
     else hipLaunchKernelGGL((celeba_tail_fwd16_kernel<128, false>), dim3(a.n_rows * 8), dim3(256), lds16, s, a);
 }

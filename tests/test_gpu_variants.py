@@ -107,6 +107,35 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
 
 
+@pytest.mark.parametrize("B,wgs", [(70, 512), (3, 512), (40, 100)])
+def test_celeba_role_split_forward_tail_reproduces_the_band_kernel(B, wgs):
+    """celeba_tail_fwd_split_kernel (persistent 8-wave workgroups, GEMM waves and gather waves on half-bands; option
+    tail_fwd_split = workgroups) against celeba_tail_fwd16_kernel: every P entry is the same k-ordered MFMA chain and the
+    taps are added in the same order, so y and da6 -- hence the reconstructions and the latents after L steps -- are BIT-identical;
+    the per-row loss is a sum of the same squares in another grouping (64 partials per row instead of 32): float32 rounding."""
+    a = archs.make_arch("celeba")
+    R = 10
+    gan, p = _make("celeba", R=R, L=3)
+    rs = np.random.RandomState(17)
+    x = np.asarray(gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=18)
+    z0 = synth.make_z(B * R, 128, seed=19)
+    ref = _run(gan, x, z0)
+    g2, _ = _make("celeba", R=R, L=3)
+    g2.set_option("tail_fwd_split", wgs)
+    got = _run(g2, x, z0)
+    assert np.array_equal(got["z"], ref["z"]) and np.array_equal(got["rec"], ref["rec"])
+    np.testing.assert_allclose(got["loss"], ref["loss"], rtol=2e-6)
+    assert np.array_equal(got["idx"], ref["idx"]) or np.allclose(np.sort(ref["loss"].reshape(B, R), axis=1)[:, 0],
+                                                                 np.sort(ref["loss"].reshape(B, R), axis=1)[:, 1], rtol=1e-5)
+    # one loop body: y, loss, dz
+    z = (rs.standard_normal((B * R, 128)) * 0.15).astype(np.float32)
+    y0, l0, d0 = gan.loss_grad(x, z)
+    y1, l1, d1 = g2.loss_grad(x, z)
+    assert np.array_equal(y1, y0) and np.array_equal(d1, d0)
+    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+
+
 def test_measurement_options_are_refused_by_the_product_library():
     """The product library carries no measurement kernels: their options fail loudly instead of being ignored."""
     from defensegan_amd import _native
