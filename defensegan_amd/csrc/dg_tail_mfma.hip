@@ -778,6 +778,13 @@ __global__ __launch_bounds__(384) void celeba_tail_fwd_mfma_kernel(CelebaTailArg
 // workgroups per CU (LDS) = 3 waves per SIMD overlap these serial phases to 51 % MFMA occupancy.  (e) a persistent form that
 // keeps all filter fragments in registers needs 80 + 64 + 16 registers before addressing: spills at 3 waves per SIMD.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// da6 = d(loss)/d(pre-activation) of one output: (2/P) (y - x) (1 - y^2), as three rounded products / one difference.  Pinned
+// (no fused multiply-add contraction) so that every formulation of the forward tail produces the same bits.
+__device__ __forceinline__ float celeba_da6(float gscale, float d, float y) {
+#pragma clang fp contract(off)
+    const float yy = y * y;
+    return (gscale * d) * (1.0f - yy);
+}
 constexpr int CE16_PITCH = 17;
 constexpr int CE16_UNIT = 32 * CE16_PITCH;                 // floats per (row, kh) unit
 constexpr int CE16_UNITS = 20;
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
             const float d = y - xv[r];
             sq = __builtin_fmaf(d, d, sq);
             const int oi = i * 192 + (tailw ? cjs[c3] : cjs[0]);
-            grow[oi] = gscale * d * (1.0f - y * y);
+            grow[oi] = celeba_da6(gscale, d, y);
             if (yrow) yrow[oi] = y;
         }
     }
@@ -1236,7 +1243,7 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
                 const float d = y - xv[co];
                 sq = __builtin_fmaf(d, d, sq);
                 yv[co] = y;
-                gv[co] = gscale * d * (1.0f - y * y);
+                gv[co] = celeba_da6(gscale, d, y);
             }
 #pragma unroll
             for (int co = 0; co < 3; ++co) a.g6[oi + co] = gv[co];
