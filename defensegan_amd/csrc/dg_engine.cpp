@@ -151,7 +151,8 @@ struct dg_handle {
     int tail_bwd_bands = 1;
     int tail_fwd16 = 1;
     int tail_bwd_persist = 512;
-    int tail_fwd_split = 0;        // CelebA forward tail: workgroups of the role-split persistent kernel (0 = celeba_tail_fwd16_kernel)
+    int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
+                                   // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
@@ -771,6 +772,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.F6p = h->tail_pack16;
         t.bwd_persist = h->tail_bwd_persist;
         t.fwd_split = (last.cin == 64) ? h->tail_fwd_split : 0;
+        t.want_loss = want_loss ? 1 : 0;
 #ifdef DG_MEASURE
         t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
         t.fwd16 = h->tail_fwd16;

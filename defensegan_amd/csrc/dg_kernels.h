@@ -109,6 +109,8 @@ struct CelebaTailArgs {
     int C;
     int do_backward;
     int bwd_persist;     // backward tail: workgroups of the persistent pipelined kernel (> 0)
+    int want_loss;       // 0: nobody reads the per-row loss of this launch (199 of the 200 forward passes of a projection): the
+                         // forward tail skips its squared-error reduction and leaves loss_part untouched
     int fwd_split;       // forward tail (C = 64): > 0 = role-split persistent kernel on half-bands with this many workgroups; 0 = celeba_tail_fwd16_kernel
 #ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 = skip the gather phase, 2 = skip the GEMM phase

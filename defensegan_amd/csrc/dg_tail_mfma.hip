@@ -1017,11 +1017,14 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
         }
     }
     mark(7);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
     // per-wave partial sums: celeba_loss_finish_kernel adds them as ((w0 + w1) + (w2 + w3)), band by band -- the order a
-    // workgroup-level reduction here used to have, without its LDS round trip and barrier at the end of every workgroup
-    if (lane == 0) a.loss_part[((long long)n * 8 + band) * 4 + wave] = sq;
+    // workgroup-level reduction here used to have, without its LDS round trip and barrier at the end of every workgroup.
+    // Only when somebody reads the loss of this launch (the last forward pass of a projection, dg_loss_grad).
+    if (a.want_loss) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+        if (lane == 0) a.loss_part[((long long)n * 8 + band) * 4 + wave] = sq;
+    }
     if constexpr (TRACE) {
         if (tr && lane == 0) {
             mark(8);
@@ -1050,6 +1053,13 @@ __global__ __launch_bounds__(256) void celeba_tail_fwd16_kernel(CelebaTailArgs a
 // two workgroups per CU.  G wave g owns output row il = g (its kh terms are wave-uniform), lane l the column j = l with its three
 // channels (12 contiguous bytes per lane for x, y and da6).  Sums keep the order of celeba_tail_fwd16_kernel (kh ascending, kw
 // ascending; one k-ordered MFMA chain per P entry): y and da6 are bit-identical to it.
+// Measured (N = 1280, one box, A/B): 176.9 -> 137.8 us at 512 workgroups (2 per CU; 448 / 480 / 768: 169 / 159 / 157).  In-kernel
+// trace (tools/tail_trace_split.py, cycles per step at ~2.0 GHz): M waves 4.06 k for fragment reads + 8 DMA pieces + 80 MFMAs
+// (2.56 k of matrix-pipe time), 1.6 k waiting for the G waves, 1.6 k for the P stores and the second barrier; G waves 5.4 k per
+// gather: the G waves are the longer side, and the SIMD's issue rate is the resource (a step issues ~2600 wave-instructions per
+// workgroup; a SIMD issues one per ~4 cycles): each round of instruction-count reduction (per-row / per-border instantiations
+// with immediate LDS offsets, buffer-descriptor DMA without address VALU, the squared-error reduction only when the loss is
+// read) bought 3-5 us.  The step is two barriers; a double-buffered P (one barrier) does not fit two workgroups per CU.
 constexpr int CES_UNITS = 10;
 constexpr int CES_PBUF = CES_UNITS * CE16_UNIT;          // floats of the P buffer
 // P slot of unit (lr, kh): lr0 -> kh - 3, lr1 -> 1 + kh, lr2 -> 6 + kh, lr3 -> 9
@@ -1059,10 +1069,11 @@ __device__ __forceinline__ constexpr int ces_slot(int lr, int kh) { return lr ==
 // it does not wait for outstanding global / LDS-DMA traffic (vmcnt), which the M waves keep in flight across steps on purpose.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// (the body is a __device__ function: hipcc's host pass instantiates the body of a __global__ template and knows neither
+// __amdgpu_buffer_rsrc_t nor the buffer-load builtins -- the kernel would silently lose its host stub)
 template <int C>
-__global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTailArgs a, int n_items) {
+__device__ __forceinline__ void celeba_tail_fwd_split_body(const CelebaTailArgs& a, int n_items, char* smem) {
     static_assert(C == 64, "position half = 16 positions x 64 channels = one 4 KB run; other widths use celeba_tail_fwd16_kernel");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KK = C / 16, CH = C / 4, ROWB = 32 * C * 4;
     char* stage = smem;                                               // [4 rows][32 positions][C]
     float* sP = reinterpret_cast<float*>(smem + 4 * ROWB);            // [CES_UNITS][32][17]
@@ -1073,7 +1084,8 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
     auto item_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
     for (int i = tid; i < 5 * KK * 64; i += 512)
         reinterpret_cast<f32x4v*>(sW)[i] = reinterpret_cast<const f32x4v*>(a.F6p)[i];
-
+    // (Measured and removed: delaying one of a CU's two workgroups by 2-8 k cycles to de-phase them, 152.0-153.4 vs 152.1 us;
+    // s_setprio 2 for the M waves, 149.6 vs 150.3 us.)
     if (wave < 4) {
         // ================================================ M role ================================================
         const int m = wave & 1;
@@ -1083,18 +1095,25 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
         char* stA = stage + lrA * ROWB + m * 16 * (C * 4);
         char* stB = stage + lrB * ROWB + m * 16 * (C * 4);
         auto row_ok = [&](int item, int lr) { const int oh = 2 * (item & 15) - 1 + lr; return oh >= 0 && oh < 32; };
+        // LDS-DMA through a buffer descriptor (base = the latent row's input map): the per-lane byte offsets of the four 1 KB
+        // pieces of a half-row are computed once, the half-row's offset rides in an SGPR -- no address VALU per piece
+        unsigned voff[16 * CH / 64];
+#pragma unroll
+        for (int q = 0; q < 16 * CH / 64; ++q) {
+            const int slot = q * 64 + lane;
+            const int pos = slot / CH, c = slot % CH;
+            voff[q] = (unsigned)(pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4));
+        }
         auto stage_half = [&](int item, int lr, char* dst) {
             if (!row_ok(item, lr)) return;
             const int n = item >> 4, oh = 2 * (item & 15) - 1 + lr;
-            const char* src = reinterpret_cast<const char*>(a.h5 + (long long)n * (1024 * C) + (long long)(oh * 32 + 16 * m) * C);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.h5 + (long long)n * (1024 * C)), 0, 1024 * C * 4, 0x00020000);
+            const int soff = (oh * 32 + 16 * m) * (C * 4);
 #pragma unroll
-            for (int q = 0; q < 16 * CH / 64; ++q) {
-                const int slot = q * 64 + lane;
-                const int pos = slot / CH, c = slot % CH;
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
-                    (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, CE16_DMA_AUX);
-            }
+            for (int q = 0; q < 16 * CH / 64; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff[q], soff, 0,
+                                                         CE16_DMA_AUX);
         };
         auto read_frags = [&](const char* st, f32x4v (&av)[KK]) {
 #pragma unroll
@@ -1117,39 +1136,54 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
             }
 #pragma unroll
             for (int c = 0; c < 5; ++c) acc[c] = z4;
-            auto chains = [&](auto cls_tag) {
+            // Specialised on (class, row B present): no branch sits between the MFMAs; the filter fragments of k-group kk + 1 are
+            // requested before the 20 (16) MFMAs of k-group kk and pinned there (left alone hipcc emits read - wait - multiply).
+            auto chains = [&](auto cls_tag, auto hasb_tag) {
                 constexpr bool C0 = decltype(cls_tag)::value;
+                constexpr bool HB = decltype(hasb_tag)::value;
                 constexpr int NA = C0 ? 4 : 3;
+                constexpr int NC = HB ? 5 : NA;
+                f32x4v wk[2][5];
+                auto read_w = [&](int kk, f32x4v (&dst)[5]) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int kh = C0 ? (c < 4 ? c + 1 : 0) : c;
+                        dst[c] = *reinterpret_cast<const f32x4v*>(sW + (((kh * KK + kk) * 64 + lane) << 2));
+                    }
+                };
+                read_w(0, wk[0]);
+                __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    f32x4v wk[5];
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) {
-                        const int kh = C0 ? (c < 4 ? c + 1 : 0) : c;
-                        wk[c] = *reinterpret_cast<const f32x4v*>(sW + (((kh * KK + kk) * 64 + lane) << 2));
-                    }
+                    if (kk + 1 < KK) read_w(kk + 1, wk[(kk + 1) & 1]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
-                        for (int c = 0; c < 5; ++c) {
-                            if (c < NA) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[kk][e], wk[c][e], acc[c], 0, 0, 0);
-                            else if (okB) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[kk][e], wk[c][e], acc[c], 0, 0, 0);
+                        for (int c = 0; c < NC; ++c) {
+                            if (c < NA) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avA[kk][e], wk[kk & 1][c][e], acc[c], 0, 0, 0);
+                            else acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(avB[kk][e], wk[kk & 1][c][e], acc[c], 0, 0, 0);
                         }
+                    if (kk + 1 < KK) __builtin_amdgcn_sched_group_barrier(0x100, NC, 0);      // DS reads of kk + 1 first ...
+                    __builtin_amdgcn_sched_group_barrier(0x8, 4 * NC, 0);                     // ... then this k-group's MFMAs
                 }
             };
-            if (cls0) chains(std::true_type()); else chains(std::false_type());
+            if (cls0) { if (okB) chains(std::true_type(), std::true_type()); else chains(std::true_type(), std::false_type()); }
+            else { if (okB) chains(std::false_type(), std::true_type()); else chains(std::false_type(), std::false_type()); }
         };
-        auto store_p = [&]() {
+        float* const pw = sP + (16 * m + 4 * fg) * CE16_PITCH + fi;     // this lane's first P entry inside a unit
+        auto store_cls = [&](auto cls_tag) {
+            constexpr bool C0 = decltype(cls_tag)::value;
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
-                const int slot = cls0 ? (c < 4 ? ces_slot(1, c + 1) : ces_slot(3, 0)) : (c < 3 ? ces_slot(2, c) : ces_slot(0, c));
-                if ((cls0 ? c < 4 : c < 3) || okB) {
-                    float* pu = sP + slot * CE16_UNIT;
+                constexpr int NA = C0 ? 4 : 3;
+                const int slot = C0 ? (c < 4 ? ces_slot(1, c + 1) : ces_slot(3, 0)) : (c < 3 ? ces_slot(2, c) : ces_slot(0, c));
+                if (c < NA || okB) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pu[(16 * m + 4 * fg + r) * CE16_PITCH + fi] = acc[c][r];
+                    for (int r = 0; r < 4; ++r) pw[slot * CE16_UNIT + r * CE16_PITCH] = acc[c][r];   // immediate offsets
                 }
             }
         };
+        auto store_p = [&]() { if (cls0) store_cls(std::true_type()); else store_cls(std::false_type()); };
         // prologue: rows of item 0; every compute(item k) sends item k + 1's rows out as soon as it has read its own
         stage_half(item_of(0), lrA, stA);
         stage_half(item_of(0), lrB, stB);
@@ -1158,16 +1192,45 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
         compute(item_of(0));
         store_p();
         lds_barrier();
+#ifdef DG_MEASURE
+        const bool tr = a.trace != nullptr && wave == 0 && blockIdx.x < 2048;
+        long long ph[4] = {0, 0, 0, 0};
+#endif
         for (int s = 0; s < n_my; ++s) {
             const bool more = s + 1 < n_my;
+#ifdef DG_MEASURE
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (tr) c0 = (long long)__builtin_readcyclecounter();
+#endif
             if (more) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // item s + 1's half-rows (issued one step ago) have landed
+#ifdef DG_MEASURE
+                if (tr) c1 = (long long)__builtin_readcyclecounter();
+#endif
                 compute(item_of(s + 1));
             }
+#ifdef DG_MEASURE
+            if (tr) c2 = (long long)__builtin_readcyclecounter();
+#endif
             lds_barrier();                                           // the G waves have read P of item s
+#ifdef DG_MEASURE
+            if (tr) c3 = (long long)__builtin_readcyclecounter();
+#endif
             if (more) store_p();
             lds_barrier();
+#ifdef DG_MEASURE
+            if (tr && more && s >= 2) {
+                ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += (long long)__builtin_readcyclecounter() - c3;
+            }
+#endif
         }
+#ifdef DG_MEASURE
+        if (tr && lane == 0) {
+            long long* o = a.trace + (long long)blockIdx.x * 16;
+            for (int i = 0; i < 4; ++i) o[i] = ph[i];
+            o[4] = n_my > 3 ? n_my - 3 : 0;
+        }
+#endif
     } else {
         // ================================================ G role ================================================
         const int g = wave - 4;                                          // output row il of the half-band
@@ -1192,48 +1255,46 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
         }
         // kh terms of row il = g in ascending kh (the order celeba_tail_fwd16_kernel adds them in): P slot and input row lr
         //   il 0: kh 1 (lr1), 3 (lr0)      il 1: kh 0 (lr2), 2 (lr1), 4 (lr0)      il 2: kh 1 (lr2), 3 (lr1)      il 3: kh 0 (lr3), 2 (lr2), 4 (lr1)
-        const int nt = (g & 1) ? 3 : 2;
-        int tslot[3], tlr[3];
-        if (g == 0) { tslot[0] = ces_slot(1, 1); tlr[0] = 1; tslot[1] = ces_slot(0, 3); tlr[1] = 0; tslot[2] = ces_slot(1, 1); tlr[2] = 1; }
-        else if (g == 1) { tslot[0] = ces_slot(2, 0); tlr[0] = 2; tslot[1] = ces_slot(1, 2); tlr[1] = 1; tslot[2] = ces_slot(0, 4); tlr[2] = 0; }
-        else if (g == 2) { tslot[0] = ces_slot(2, 1); tlr[0] = 2; tslot[1] = ces_slot(1, 3); tlr[1] = 1; tslot[2] = ces_slot(2, 1); tlr[2] = 2; }
-        else { tslot[0] = ces_slot(3, 0); tlr[0] = 3; tslot[1] = ces_slot(2, 2); tlr[1] = 2; tslot[2] = ces_slot(1, 4); tlr[2] = 1; }
+        // The gather is instantiated per row (G is a compile-time constant): the P slots become immediate offsets of the reads.
+        // image of a latent row: n / R by a 40-bit magic multiply on the scalar unit (exact for n < 2^24, R < 2^16)
+        const unsigned long long magicR = ((1ULL << 40) + (unsigned)a.R - 1) / (unsigned)a.R;
+        const int j3 = 3 * j;
         auto load_x = [&](int item, float (&xv)[3]) {
             const int n = item >> 4, hb = item & 15;
-            const float* xrow = a.x + (long long)((unsigned)n / (unsigned)a.R) * 12288 + (4 * hb + g) * 192 + 3 * j;
+            const long long b = (long long)(((unsigned long long)(unsigned)n * magicR) >> 40);
+            const float* xrow = a.x + (b * 12288 + (4 * hb + g) * 192);          // wave-uniform base, lane offset j3
 #pragma unroll
-            for (int co = 0; co < 3; ++co) xv[co] = xrow[co];
+            for (int co = 0; co < 3; ++co) xv[co] = xrow[j3 + co];
         };
-        auto gather = [&](int item, const float (&xv)[3]) {
+        // Instantiated per (row G, missing input row): every P slot is an immediate offset of its read and nothing is masked.
+        // MISS = 1: hb == 0, input row lr0 (oh = -1) does not exist;  MISS = 2: hb == 15, lr3 (oh = 32) does not exist.
+        auto gather_g = [&](auto g_tag, auto miss_tag, int item, const float (&xv)[3]) {
+            constexpr int G = decltype(g_tag)::value;
+            constexpr int MISS = decltype(miss_tag)::value;
+            constexpr int NT = (G & 1) ? 3 : 2;
+            constexpr int TS[4][3] = {{ces_slot(1, 1), ces_slot(0, 3), ces_slot(1, 1)}, {ces_slot(2, 0), ces_slot(1, 2), ces_slot(0, 4)},
+                                      {ces_slot(2, 1), ces_slot(1, 3), ces_slot(2, 1)}, {ces_slot(3, 0), ces_slot(2, 2), ces_slot(1, 4)}};
+            constexpr int TL[4][3] = {{1, 0, 1}, {2, 1, 0}, {2, 1, 2}, {3, 2, 1}};
             const int n = item >> 4, hb = item & 15;
             float tv[3][9];
-            bool use[3];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int oh = 2 * hb - 1 + tlr[t];
-                use[t] = t < nt && oh >= 0 && oh < 32;                      // wave-uniform
-                // a term that does not exist (third kh of an even row, a row outside the image) re-reads a slot that does and is
-                // not summed: its own slot holds whatever an earlier item left there
-                const float* pu = sP + (use[t] ? tslot[t] : ces_slot(1, 1 + g)) * CE16_UNIT;
+            for (int t = 0; t < NT; ++t) {
+                if ((MISS == 1 && TL[G][t] == 0) || (MISS == 2 && TL[G][t] == 3)) continue;
+                const float* pu = sP + TS[G][t] * CE16_UNIT;
 #pragma unroll
                 for (int co = 0; co < 3; ++co)
 #pragma unroll
                     for (int aw = 0; aw < 3; ++aw) tv[co][t * 3 + aw] = pu[colofs[co][aw]];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int co = 0; co < 3; ++co)
-#pragma unroll
-                for (int q = 0; q < 9; ++q) asm volatile("" : "+v"(tv[co][q]));
             float sq = 0.f;
-            const long long oi = (long long)n * 12288 + (4 * hb + g) * 192 + 3 * j;
             float yv[3], gv[3];
 #pragma unroll
             for (int co = 0; co < 3; ++co) {
                 float sacc = 0.f;
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    if (!use[t]) continue;
+                for (int t = 0; t < NT; ++t) {
+                    if ((MISS == 1 && TL[G][t] == 0) || (MISS == 2 && TL[G][t] == 3)) continue;
 #pragma unroll
                     for (int aw = 0; aw < 3; ++aw) sacc += tv[co][t * 3 + aw];
                 }
@@ -1245,29 +1306,75 @@ __global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTai
                 yv[co] = y;
                 gv[co] = celeba_da6(gscale, d, y);
             }
+            const long long ob = (long long)n * 12288 + (4 * hb + G) * 192;           // wave-uniform
+            float* grow = a.g6 + ob;
 #pragma unroll
-            for (int co = 0; co < 3; ++co) a.g6[oi + co] = gv[co];
+            for (int co = 0; co < 3; ++co) grow[j3 + co] = gv[co];
             if (a.y) {
+                float* yrow = a.y + ob;
 #pragma unroll
-                for (int co = 0; co < 3; ++co) a.y[oi + co] = yv[co];
+                for (int co = 0; co < 3; ++co) yrow[j3 + co] = yv[co];
             }
+            if (a.want_loss) {          // read only after the last forward pass of a projection and by dg_loss_grad
 #pragma unroll
-            for (int mm = 32; mm >= 1; mm >>= 1) sq += __shfl_xor(sq, mm, 64);
-            if (lane == 0) a.loss_part[((long long)n * 16 + hb) * 4 + g] = sq;
+                for (int mm = 32; mm >= 1; mm >>= 1) sq += __shfl_xor(sq, mm, 64);
+                if (lane == 0) a.loss_part[((long long)n * 16 + hb) * 4 + G] = sq;
+            }
+        };
+        auto gather_m = [&](auto g_tag, int item, const float (&xv)[3]) {
+            const int hb = item & 15;
+            if (hb == 0) gather_g(g_tag, std::integral_constant<int, 1>(), item, xv);
+            else if (hb == 15) gather_g(g_tag, std::integral_constant<int, 2>(), item, xv);
+            else gather_g(g_tag, std::integral_constant<int, 0>(), item, xv);
+        };
+        auto gather = [&](int item, const float (&xv)[3]) {
+            if (g == 0) gather_m(std::integral_constant<int, 0>(), item, xv);
+            else if (g == 1) gather_m(std::integral_constant<int, 1>(), item, xv);
+            else if (g == 2) gather_m(std::integral_constant<int, 2>(), item, xv);
+            else gather_m(std::integral_constant<int, 3>(), item, xv);
         };
         lds_barrier();
         lds_barrier();
+#ifdef DG_MEASURE
+        const bool tr = a.trace != nullptr && wave == 4 && blockIdx.x < 2048;
+        long long gph[3] = {0, 0, 0};
+#endif
         for (int s = 0; s < n_my; ++s) {
             // x of this item is requested first and used last (after the LDS reads and the tanh): its L2 latency sits under them.
             // (Requesting it a step ahead does not help: the wait for it is a vmcnt(0), which would then also wait for the
             // request just issued for the step after.)
+#ifdef DG_MEASURE
+            long long c0 = 0, c1 = 0, c2 = 0;
+            if (tr) c0 = (long long)__builtin_readcyclecounter();
+#endif
             float xv[3];
             load_x(item_of(s), xv);
             gather(item_of(s), xv);
+#ifdef DG_MEASURE
+            if (tr) c1 = (long long)__builtin_readcyclecounter();
+#endif
             lds_barrier();
+#ifdef DG_MEASURE
+            if (tr) c2 = (long long)__builtin_readcyclecounter();
+#endif
             lds_barrier();
+#ifdef DG_MEASURE
+            if (tr && s >= 2 && s + 1 < n_my) { gph[0] += c1 - c0; gph[1] += c2 - c1; gph[2] += (long long)__builtin_readcyclecounter() - c2; }
+#endif
         }
+#ifdef DG_MEASURE
+        if (tr && lane == 0) {
+            long long* o = a.trace + (long long)blockIdx.x * 16 + 8;
+            for (int i = 0; i < 3; ++i) o[i] = gph[i];
+        }
+#endif
     }
+}
+
+template <int C>
+__global__ __launch_bounds__(512, 4) void celeba_tail_fwd_split_kernel(CelebaTailArgs a, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    celeba_tail_fwd_split_body<C>(a, n_items, smem);
 }
 
 #ifdef DG_MEASURE   // the per-band backward kernel, superseded by the persistent one: kept as a cross-check (option tail_bwd_persist = 0)

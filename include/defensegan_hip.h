@@ -156,6 +156,8 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "nsplit"           split-K factor of the Linear backward (default 16)
  *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
+ *   "tail_fwd_split"   CelebA forward tail (NET_DIM 64): workgroups of the role-split persistent kernel (default 512 = two per CU);
+ *                      0 = the per-band kernel (celeba_tail_fwd16_kernel; same y and da6 bit for bit, the per-row loss to rounding)
  *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel
  * Only in the measurement build of the library (same sources with -DDG_MEASURE -> libdefensegan_hip_measure.so; the product
  * library refuses them): "tail_fwd16" = 0 (32x32x2 CelebA forward tail), "tail_bwd_persist" = 0 + "tail_bwd_bands" (per-band

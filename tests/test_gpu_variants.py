@@ -109,8 +109,8 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
 
 @pytest.mark.parametrize("B,wgs", [(70, 512), (3, 512), (40, 100)])
 def test_celeba_role_split_forward_tail_reproduces_the_band_kernel(B, wgs):
-    """celeba_tail_fwd_split_kernel (persistent 8-wave workgroups, GEMM waves and gather waves on half-bands; option
-    tail_fwd_split = workgroups) against celeba_tail_fwd16_kernel: every P entry is the same k-ordered MFMA chain and the
+    """celeba_tail_fwd_split_kernel (persistent 8-wave workgroups, GEMM waves and gather waves on half-bands; the default for
+    64 channels, option tail_fwd_split = workgroups) against celeba_tail_fwd16_kernel (tail_fwd_split = 0): every P entry is the same k-ordered MFMA chain and the
     taps are added in the same order, so y and da6 -- hence the reconstructions and the latents after L steps -- are BIT-identical;
     the per-row loss is a sum of the same squares in another grouping (64 partials per row instead of 32): float32 rounding."""
     a = archs.make_arch("celeba")
@@ -120,6 +120,7 @@ def test_celeba_role_split_forward_tail_reproduces_the_band_kernel(B, wgs):
     x = np.asarray(gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))
     x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=18)
     z0 = synth.make_z(B * R, 128, seed=19)
+    gan.set_option("tail_fwd_split", 0)                 # the per-band kernel is the reference here
     ref = _run(gan, x, z0)
     g2, _ = _make("celeba", R=R, L=3)
     g2.set_option("tail_fwd_split", wgs)
