@@ -776,6 +776,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
 #ifdef DG_MEASURE
         t.F6p = h->tail_fwd16 ? h->tail_pack16 : h->tail_pack;
         t.fwd16 = h->tail_fwd16;
+        if (!h->tail_fwd16) t.fwd_split = 0;          // the 32-wide cross-check kernel was asked for
         t.trace = h->d_tail_trace;
         t.dbg = h->tail_dbg;
         t.bwd_bands = h->tail_bwd_bands;

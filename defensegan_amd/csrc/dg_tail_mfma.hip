@@ -23,6 +23,11 @@ namespace dg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are complete, then s_barrier.  Unlike __syncthreads()
+// it does not wait for outstanding global / LDS-DMA traffic (vmcnt), which the M waves keep in flight across steps on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
 // ---- forward GEMM of one 32-position tile: P[q0 .. q0+31][0 .. 32*NT) -> LDS --------------------------------
 // hrow: base of this latent row's input map [positions][C]; gp = global position index of this lane's row or -1.
 template <int C>
@@ -343,6 +348,8 @@ __global__ __launch_bounds__(256) void mnist_tail_mfma_kernel(MnistTailArgs a) {
 //     G:  gather + sigmoid + loss + da5 image of row t
 // with P, the da5 image and the ReluGrad bits double-buffered by row parity, so the three stages of three consecutive
 // rows overlap and the A fragments have a whole step to arrive.  Rows of a workgroup: blockIdx.x + k * gridDim.x.
+// (Round 3: the barriers here are __syncthreads(), whose fence also waits for vmcnt(0) -- the row stores' acknowledgements and
+// the DMA of row t + 2; LDS-only barriers (lds_barrier) measured the same, 66.2 vs 66.5 us: by the end of a step they have arrived.)
 // Measured (tools/tail_trace_mnist.py, N = 2560): 86 -> 78 us; a step is ~17 k cycles of which the 8 DMA instructions
 // take 2.4 k and the 32 row stores ~3 k to ISSUE (the memory pipes are saturated in bursts: 100 KB per CU per step);
 // spreading them between the forward MFMA groups made it worse (125 us: every stalled VMEM issue then blocks MFMAs);
@@ -1064,10 +1071,6 @@ constexpr int CES_UNITS = 10;
 constexpr int CES_PBUF = CES_UNITS * CE16_UNIT;          // floats of the P buffer
 // P slot of unit (lr, kh): lr0 -> kh - 3, lr1 -> 1 + kh, lr2 -> 6 + kh, lr3 -> 9
 __device__ __forceinline__ constexpr int ces_slot(int lr, int kh) { return lr == 0 ? kh - 3 : lr == 1 ? 1 + kh : lr == 2 ? 6 + kh : 9; }
-
-// Workgroup barrier for LDS hand-offs only: this wave's LDS operations are complete, then s_barrier.  Unlike __syncthreads()
-// it does not wait for outstanding global / LDS-DMA traffic (vmcnt), which the M waves keep in flight across steps on purpose.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // (the body is a __device__ function: hipcc's host pass instantiates the body of a __global__ template and knows neither
 // __amdgpu_buffer_rsrc_t nor the buffer-load builtins -- the kernel would silently lose its host stub)
