@@ -39,7 +39,7 @@ def main():
     min_calls = int(rest[0]) if rest else 64
 
     def layer_of(name, mean_ns):
-        cands = [k for k in layers if k["kernel"] == name]
+        cands = [k for k in layers if k["kernel"] == name or k["kernel"] == name.split("<")[0]]
         if not cands:
             return ""
         best = min(cands, key=lambda k: abs(k["avg_us"] * 1e3 - mean_ns))
