@@ -40,6 +40,8 @@ SYMBOLS = [
     ("dg_profile_reset", _i, [_vp]),
     ("dg_debug_read", _i64, [_vp, _cp, _vp, _i64]),
     ("dg_set_option", _i, [_vp, _cp, _cp]),
+    ("dg_export_tuning", _i64, [_vp, _vp, _i64]),
+    ("dg_import_tuning", _i, [_vp, _cp]),
     ("dg_clf_create", _i, [_i, _i, _i, _i, C.POINTER(_vp)]),
     ("dg_clf_destroy", _i, [_vp]),
     ("dg_clf_add_layer", _i, [_vp, _i, _i, _i, _i, _i, _i, _i]),

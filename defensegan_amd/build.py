@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libdefensegan_hip.so")
 # the same sources with -DDG_MEASURE: in-kernel phase traces, phase-removal switches and the superseded tail kernels kept as
 # cross-checks (tools/, tests/test_gpu_variants.py).  Never loaded by the product path.
 LIB_MEASURE = os.path.join(LIBDIR, "libdefensegan_hip_measure.so")
-SOURCES = ["dg_engine.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_tail_mfma.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
+SOURCES = ["dg_engine.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_linear.hip", "dg_tail_mfma.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
 HEADERS = ["dg_kernels.h", "dg_device.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
 ARCH = "gfx950"
 
@@ -94,20 +94,29 @@ def _build_one(lib: str, objdir: str, defines, verbose: bool) -> None:
     subprocess.check_call(cmd)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Builds the product library and the measurement library (-DDG_MEASURE) from the same sources; returns the product's path."""
+def _fresh(lib: str, stamp: str, dig: str) -> bool:
+    return os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig
+
+
+def build(force: bool = False, verbose: bool = True, measure: bool = True) -> str:
+    """Builds the product library and (``measure``) the measurement library (-DDG_MEASURE) from the same sources; returns the
+    product's path.  Each library has its own stamp, written as soon as that library is linked: a failing measurement build
+    no longer leaves the product library looking stale."""
     os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "build.stamp")
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(LIB_MEASURE) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
-    _build_one(LIB, os.path.join(LIBDIR, "obj"), [], verbose)
-    _build_one(LIB_MEASURE, os.path.join(LIBDIR, "obj_measure"), ["-DDG_MEASURE"], verbose)
-    with open(stamp, "w") as fh:
-        fh.write(dig)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    stamp_m = os.path.join(LIBDIR, "build_measure.stamp")
+    if force or not _fresh(LIB, stamp, dig):
+        _build_one(LIB, os.path.join(LIBDIR, "obj"), [], verbose)
+        with open(stamp, "w") as fh:
+            fh.write(dig)
+    if measure and (force or not _fresh(LIB_MEASURE, stamp_m, dig)):
+        _build_one(LIB_MEASURE, os.path.join(LIBDIR, "obj_measure"), ["-DDG_MEASURE"], verbose)
+        with open(stamp_m, "w") as fh:
+            fh.write(dig)
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, measure="--no-measure" not in sys.argv)
     print(LIB)

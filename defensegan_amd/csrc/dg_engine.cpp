@@ -74,6 +74,9 @@ struct ActInfo {
 struct JobList {
     int n_rows = 0, n_jobs = 0, min_level = 0;
     int xcd_order = 0;             // 1 = head of the list re-arranged for XCD locality (dg_plan.h order_for_xcd)
+    int snake = 0;                 // 1 = every other round of #CUs jobs reversed (boustrophedon)
+    double slack = 0.0;            // the cutting threshold the list was built with (dg_plan.h build_jobs)
+    double xcd_head = 0.0;         // head fraction of the XCD-locality order
     double predicted_us = 0.0;     // simulated makespan of the cost model
     double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
     dg::JobDesc* d_jobs = nullptr;
@@ -130,6 +133,12 @@ struct dg_handle {
     // result does not depend on the batch).  Measured 8 vs 16 (MI355X): 2560 rows 977.6 vs 975.5 img/s, 500 rows (the
     // reference's default batch) 756.6 vs 777.9, CelebA 305.2 vs 305.2.
     int nsplit = 16;
+    // The latent turn (Linear backward -> update -> Linear forward) on the weight-stationary kernels of dg_linear.hip when the
+    // shapes allow (any latent_dim that is a multiple of 32 up to 192 forward; latent_dim 128 and 256-wide K slices backward);
+    // 0 = the position-batched kernel as for every other layer.  Bit-identical either way (same fma chains, same K slices).
+    int latent_turn = 1;
+    int lin_groups_fwd = 0, lin_groups_bwd = 0;   // workgroups per column tile / K slice; 0 = pick from the CU count
+    int cu_count = 256;
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
     // Resident workgroups per CU by (family, smallest level in the list) = what LDS admits: 160 KB / (64 | 80, 48, 32 KB of
     // gemm_lds_bytes) = 2, 3, 5.  The kernel's __launch_bounds__(256, 2 / 3 / 4) is the MINIMUM occupancy the register allocator
@@ -178,6 +187,20 @@ struct dg_handle {
     double* bn_part = nullptr;     // BN partial sums scratch
     float* g6 = nullptr;           // CelebA: da6 [N, 64*64*3]
     float* loss_part = nullptr;    // CelebA: [N, 8 bands, 4 waves] partial sums of squared error
+
+    // Replayed graphs of the L-step loop (option graph_max_rows): for call shapes of at most that many latent rows -- where a
+    // kernel lasts tens of microseconds and the ~1600 host enqueues of a call are a visible share -- dg_reconstruct captures the
+    // loop once per (B, R, L, lr, momentum, schedule) on an internal stream and replays it on the caller's.  Graph nodes hold
+    // fixed pointers: the loop reads the call's images from a staging copy (xbuf), and a graph dies with the job lists /
+    // workspace it points into (list_epoch).
+    struct LoopGraph { int B = 0, R = 0, L = 0; float lr = 0.f, momentum = 0.f; int lr_intended = 0; uint64_t epoch = 0; hipGraphExec_t exec = nullptr; };
+    std::vector<LoopGraph> graphs;
+    uint64_t list_epoch = 0;
+    int graph_max_rows = 1024;
+    bool graph_broken = false;     // a capture / instantiate failed once: stay on the eager path
+    float* xbuf = nullptr;
+    int64_t xbuf_floats = 0;
+    hipStream_t cap_stream = nullptr;
 
     // profiling
     int prof_stride = 0;
@@ -259,6 +282,7 @@ int launch_check(const char* what) {
 
 // forget every tuned job list (an option that changes how the lists are built or timed was set)
 void drop_job_lists(dg_handle* h) {
+    ++h->list_epoch;
     for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
     for (auto* vec : {&h->Fd, &h->Bd})
         for (auto& op : *vec) { for (auto& jl : op.jobs) (void)hipFree(jl.d_jobs); op.jobs.clear(); }
@@ -370,7 +394,9 @@ int build_plans(dg_handle* h) {
 
 void free_workspace(dg_handle* h) {
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y); fr(h->g6); fr(h->loss_part);
+    fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y); fr(h->g6); fr(h->loss_part); fr(h->xbuf);
+    h->xbuf_floats = 0;
+    ++h->list_epoch;                 // captured loops point into these buffers
     for (auto& a : h->act) fr(a);
     for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
@@ -387,6 +413,10 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     HIP_TRY(hipMalloc(&h->part, cap * h->nsplit * h->latent * sizeof(float)));
     HIP_TRY(hipMalloc(&h->loss, cap * sizeof(float)));
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
+    if (h->graph_max_rows > 0) {
+        h->xbuf_floats = std::min<int64_t>(cap, h->graph_max_rows) * h->P;      // B <= B * R rows
+        HIP_TRY(hipMalloc(&h->xbuf, (size_t)h->xbuf_floats * sizeof(float)));
+    }
     if (h->arch == DG_ARCH_CELEBA64) {
         HIP_TRY(hipMalloc(&h->g6, cap * h->P * sizeof(float)));
         HIP_TRY(hipMalloc(&h->loss_part, cap * 64 * sizeof(float)));
@@ -479,6 +509,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             Cand c;
             c.jl.n_rows = n_rows;
             c.jl.min_level = lvl;
+            c.jl.slack = slacks[k];
             c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
                                     h->job_model, &c.jl.predicted_us, lvl);
             auto add = [&](Cand&& x) {
@@ -497,6 +528,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 Cand lx;
                 lx.jl = c.jl;
                 lx.jl.xcd_order = 1;
+                lx.jl.xcd_head = h->job_xcd_head;
                 lx.jobs = c.jobs;
                 dg::order_for_xcd(lx.jobs, n_rows, h->job_xcd_head);
                 lx.jl.predicted_us = dg::simulate_jobs(op.bplan, lx.jobs, op.family, (int)slots, h->job_model);
@@ -508,9 +540,9 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             if (tune && c.jobs.size() <= slots && c.jobs.size() > (size_t)cus) {
                 Cand sn;
                 sn.jl = c.jl;
+                sn.jl.snake = 1;
                 sn.jobs = c.jobs;
-                for (size_t g0 = (size_t)cus; g0 < sn.jobs.size(); g0 += 2 * (size_t)cus)
-                    std::reverse(sn.jobs.begin() + g0, sn.jobs.begin() + std::min(sn.jobs.size(), g0 + (size_t)cus));
+                dg::snake_order(sn.jobs, cus);
                 add(std::move(c));
                 add(std::move(sn));
             } else {
@@ -610,11 +642,59 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         op.jobs.erase(op.jobs.begin());
     }
     op.jobs.push_back(jl);
+    ++h->list_epoch;
     return &op.jobs.back();
+}
+
+// F1 / B1 on the weight-stationary kernels (dg_linear.hip)?
+bool lin_stationary(const dg_handle* h, const GemmOp& op) {
+    if (!h->latent_turn) return false;
+    if (&op == &h->F1) return h->lin_out % 128 == 0 && h->latent % 32 == 0 && dg::lin_stationary_supported(h->latent / 32, op.mode);
+    if (&op == &h->B1)
+        return h->latent == 128 && h->lin_out % (h->nsplit * 32) == 0 && dg::lin_stationary_supported(h->lin_out / h->nsplit / 32, op.mode);
+    return false;
+}
+
+int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    const bool fwd = &op == &h->F1;
+    dg::LinArgs a;
+    a.A = A;
+    a.W = op.W;
+    a.Out = Out;
+    a.bias = op.bias;
+    a.n_rows = n_rows;
+    a.mode = op.mode;
+    const int n_blocks = (n_rows + 31) / 32;
+    int want;
+    if (fwd) {
+        a.a_rowstride = h->latent; a.a_unit = 0;
+        a.w_rowstride = h->latent; a.w_unit = 128 * h->latent;
+        a.out_rowstride = h->lin_out; a.out_unit = 128;
+        a.units = h->lin_out / 128;
+        a.kch = h->latent / 32;
+        want = h->lin_groups_fwd > 0 ? h->lin_groups_fwd : std::max(1, 2 * h->cu_count / a.units);     // two workgroups per CU
+    } else {
+        const int ks = h->lin_out / h->nsplit;
+        a.a_rowstride = h->lin_out; a.a_unit = ks;
+        a.w_rowstride = h->lin_out; a.w_unit = ks;
+        a.out_rowstride = (long long)h->nsplit * h->latent; a.out_unit = h->latent;
+        a.units = h->nsplit;
+        a.kch = ks / 32;
+        want = h->lin_groups_bwd > 0 ? h->lin_groups_bwd : std::max(1, h->cu_count / a.units);         // one workgroup per CU
+    }
+    a.groups = std::min(n_blocks, want);
+    char sym[64];
+    snprintf(sym, sizeof sym, "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
+    {
+        ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
+        dg::launch_lin_stationary(a, s);
+    }
+    return launch_check(op.name.c_str());
 }
 
 // One GEMM layer: one launch with the job list prepare_rows() left for this row count.  Nothing here allocates or waits.
 int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+    if (lin_stationary(h, op)) return run_lin_stationary(h, op, A, Out, n_rows, s, prof);
     const JobList* jl = find_jobs(op, n_rows);
     if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
     const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out);
@@ -669,7 +749,7 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
         return rc;
     };
     for (int i = 0; i < n && !missing; ++i)
-        each_op([&](GemmOp& op, int, int, int) { if (!find_jobs(op, rows[i])) missing = true; return 0; });
+        each_op([&](GemmOp& op, int, int, int) { if (!lin_stationary(h, op) && !find_jobs(op, rows[i])) missing = true; return 0; });
     if (!missing) return DG_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
@@ -682,6 +762,7 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
         rc = each_op([&](GemmOp& op, int kind, int d, int) {
             const float* A = kind == 0 ? h->z : kind == 1 ? h->act[d] : kind == 2 ? h->act[d + 1] : h->act[0];
             float* Out = kind == 0 ? h->act[0] : kind == 1 ? h->act[d + 1] : kind == 2 ? h->act[d] : h->part;
+            if (lin_stationary(h, op)) return (int)DG_OK;          // no job list: dg_linear.hip derives its grid from the row count
             if (!get_jobs(h, op, nr, A, Out, s))
                 return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), nr);
             return (int)DG_OK;
@@ -849,6 +930,71 @@ int rebuild_plans(dg_handle* h) {
     return DG_OK;
 }
 
+// The L-step loop of DefenseGANBase.reconstruct (gan.py:409-437) as launches on the row groups' streams: L forwards, L - 1
+// backward + update (the reference's L-th update is dead work), the last forward also leaves y and the per-row loss.
+int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float momentum, const RowGroup* grp, int ngroups) {
+    const int steps = L > 1 ? L : 1;
+    const int decay_iter = L > 0 ? (int)std::ceil(0.8 * (double)L) : 1;
+    for (int k = 0; k < steps; ++k) {
+        const bool last = (k == steps - 1);
+        const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
+        // a step that is not sampled breaks the marker chain: the next sampled launch starts from its own marker, not from the
+        // one recorded after the last sampled step (which would charge it with every skipped step in between)
+        if (!prof) h->prof_chain_last = -1;
+        const float lr_k = h->lr_intended ? lr * std::pow(0.1f, (float)(k / decay_iter)) : lr;
+        for (int gi = 0; gi < ngroups; ++gi) {
+            const RowGroup& g = grp[gi];
+            int rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
+            if (rc) return rc;
+            if (last) continue;
+            rc = run_backward(h, g, prof);
+            if (rc) return rc;
+            ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
+            const int64_t r0 = g.row0;
+            dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
+                                       h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s);
+        }
+    }
+    return DG_OK;
+}
+
+// Graph of enqueue_steps for one call shape, reading the images from h->xbuf; nullptr = use the eager path.
+hipGraphExec_t loop_graph(dg_handle* h, int B, int R, int L, float lr, float momentum) {
+    for (auto it = h->graphs.begin(); it != h->graphs.end();) {
+        if (it->epoch != h->list_epoch) { (void)hipGraphExecDestroy(it->exec); it = h->graphs.erase(it); continue; }
+        if (it->B == B && it->R == R && it->L == L && it->lr == lr && it->momentum == momentum && it->lr_intended == h->lr_intended)
+            return it->exec;
+        ++it;
+    }
+    if (!h->cap_stream && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess) { h->graph_broken = true; return nullptr; }
+    RowGroup g;
+    g.row0 = 0; g.n_rows = B * R; g.s = h->cap_stream;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool ok = hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess;
+    if (ok) {
+        const int rc = enqueue_steps(h, h->xbuf, R, L, lr, momentum, &g, 1);
+        ok = hipStreamEndCapture(h->cap_stream, &graph) == hipSuccess && rc == DG_OK && graph != nullptr;
+    }
+    if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+        (void)hipGetLastError();
+        h->graph_broken = true;
+        return nullptr;
+    }
+    if (h->graphs.size() >= 8) { (void)hipGraphExecDestroy(h->graphs.front().exec); h->graphs.erase(h->graphs.begin()); }
+    dg_handle::LoopGraph lg;
+    lg.B = B; lg.R = R; lg.L = L; lg.lr = lr; lg.momentum = momentum; lg.lr_intended = h->lr_intended; lg.epoch = h->list_epoch; lg.exec = exec;
+    h->graphs.push_back(lg);
+    return exec;
+}
+
+void drop_graphs(dg_handle* h) {
+    for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
+    h->graphs.clear();
+}
+
 // One call processes at most 2^24 latent rows (32-bit tile arithmetic in the launchers).
 int check_rows(int B, int R, int* n_rows) {
     if (B < 1 || R < 1) return fail(DG_E_INVALID, "need B >= 1 and R >= 1 (got %d, %d)", B, R);
@@ -909,6 +1055,8 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     h->use_bn = use_bn;
     h->device = device;
     h->lin_out = 4 * 4 * 4 * net_dim;
+    (void)hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device);
+    if (h->cu_count <= 0) h->cu_count = 256;
     const int nd = net_dim;
     if (arch == DG_ARCH_MNIST28) {
         h->img_h = 28; h->img_c = 1;
@@ -962,6 +1110,8 @@ int dg_destroy(dg_handle* h) {
     if (!h) return DG_OK;
     (void)hipSetDevice(h->device);
     prof_collect(h);
+    drop_graphs(h);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
@@ -1151,23 +1301,25 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
     }
-    const int decay_iter = L > 0 ? (int)std::ceil(0.8 * (double)L) : 1;
-    for (int k = 0; k < steps; ++k) {
-        const bool last = (k == steps - 1);
-        const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
-        const float lr_k = h->lr_intended ? lr * std::pow(0.1f, (float)(k / decay_iter)) : lr;
-        for (int gi = 0; gi < ngroups; ++gi) {
-            const RowGroup& g = grp[gi];
-            rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
-            if (rc) return rc;
-            if (last) continue;
-            rc = run_backward(h, g, prof);
-            if (rc) return rc;
-            ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
-            const int64_t r0 = g.row0;
-            dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
-                                       h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s);
+    // Small prepared shapes replay a captured graph of the loop instead of enqueuing its ~8 L launches one by one
+    bool replayed = false;
+    if (h->graph_max_rows > 0 && n_rows <= h->graph_max_rows && !h->graph_broken && h->prof_stride == 0 && ngroups == 1 &&
+        steps >= 2 && (int64_t)B * h->P <= h->xbuf_floats) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            hipGraphExec_t exec = loop_graph(h, B, R, L, lr, momentum);
+            if (exec) {
+                HIP_TRY(hipMemcpyAsync(h->xbuf, x, (size_t)B * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
+                HIP_TRY(hipGraphLaunch(exec, s));
+                replayed = true;
+            }
+        } else {
+            (void)hipGetLastError();
         }
+    }
+    if (!replayed) {
+        rc = enqueue_steps(h, x, R, L, lr, momentum, grp, ngroups);
+        if (rc) return rc;
     }
     for (int gi = 1; gi < ngroups; ++gi) {
         HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
@@ -1245,6 +1397,81 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     return DG_OK;
 }
 
+// ---- tuning export / import ---------------------------------------------------------------------------------------------
+// The job list a layer runs with for a row count is chosen by TIMING candidates (get_jobs), so two processes -- the bench and a
+// profiler pass, or the ranks of a multi-GPU run -- can settle on different lists for the same layer.  Every list is a pure
+// function of (layer plan, row count, starting level, cutting threshold, order variant): exporting those few numbers and
+// importing them elsewhere reproduces the lists exactly, without timing.
+int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
+    if (!h) return fail(DG_E_INVALID, "null handle");
+    std::string out;
+    char line[256];
+    snprintf(line, sizeof line, "dgtune 1 arch %d latent %d net_dim %d use_bn %d nsplit %d cus %d\n", h->arch, h->latent, h->net_dim,
+             h->use_bn, h->nsplit, h->cu_count);
+    out += line;
+    auto dump = [&](const GemmOp& op) {
+        for (const JobList& jl : op.jobs) {
+            dg::TuneRecord r;
+            r.op = op.name; r.n_rows = jl.n_rows; r.min_level = jl.min_level; r.slack = jl.slack; r.snake = jl.snake;
+            r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us;
+            out += dg::format_tune_record(r);
+        }
+    };
+    dump(h->F1);
+    for (const auto& op : h->Fd) dump(op);
+    for (const auto& op : h->Bd) dump(op);
+    dump(h->B1);
+    const int64_t need = (int64_t)out.size() + 1;
+    if (buf && cap >= need) std::memcpy(buf, out.c_str(), (size_t)need);
+    else if (buf && cap > 0) buf[0] = 0;
+    return need;
+}
+
+int dg_import_tuning(dg_handle* h, const char* text) {
+    if (!h || !text) return fail(DG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const char* p = text;
+    int ver = 0, arch = 0, latent = 0, net_dim = 0, use_bn = 0, nsplit = 0, cus = 0, used = 0;
+    if (sscanf(p, "dgtune %d arch %d latent %d net_dim %d use_bn %d nsplit %d cus %d%n", &ver, &arch, &latent, &net_dim, &use_bn, &nsplit, &cus, &used) != 7 || ver != 1)
+        return fail(DG_E_INVALID, "not a dg_export_tuning text (header)");
+    if (arch != h->arch || latent != h->latent || net_dim != h->net_dim || use_bn != h->use_bn || nsplit != h->nsplit || cus != h->cu_count)
+        return fail(DG_E_INVALID, "tuning was exported for another configuration (arch %d latent %d net_dim %d use_bn %d nsplit %d, %d CUs)",
+                    arch, latent, net_dim, use_bn, nsplit, cus);
+    p += used;
+    std::vector<GemmOp*> ops = {&h->F1, &h->B1};
+    for (auto& op : h->Fd) ops.push_back(&op);
+    for (auto& op : h->Bd) ops.push_back(&op);
+    HIP_TRY(hipDeviceSynchronize());      // lists that are replaced may still be in use by queued launches
+    int n_imported = 0;
+    for (;;) {
+        dg::TuneRecord r;
+        if (!dg::parse_tune_record(&p, &r)) {
+            if (*p) return fail(DG_E_INVALID, "malformed tuning record near '%.40s'", p);
+            break;
+        }
+        GemmOp* op = nullptr;
+        for (GemmOp* o : ops) if (o->name == r.op) op = o;
+        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2)
+            return fail(DG_E_INVALID, "tuning record for unknown layer '%s' / bad row count %d / level %d", r.op.c_str(), r.n_rows, r.min_level);
+        JobList jl;
+        jl.n_rows = r.n_rows; jl.min_level = r.min_level; jl.slack = r.slack; jl.snake = r.snake; jl.xcd_order = r.xcd_order;
+        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us;
+        const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(op->bplan, op->family, h->cu_count, h->job_slots_per_cu[op->family][r.min_level],
+                                                                   r, h->job_model, &jl.predicted_us);
+        if ((int)jobs.size() != r.n_jobs)
+            return fail(DG_E_INVALID, "layer %s, %d rows: the record describes %d jobs, this build makes %d (other cost model or planner)",
+                        r.op.c_str(), r.n_rows, r.n_jobs, (int)jobs.size());
+        if (!upload_jobs(jl, jobs)) return fail(DG_E_NOMEM, "cannot upload the job list of layer %s", r.op.c_str());
+        for (auto it = op->jobs.begin(); it != op->jobs.end();)
+            if (it->n_rows == r.n_rows) { (void)hipFree(it->d_jobs); it = op->jobs.erase(it); } else ++it;
+        if (op->jobs.size() >= 16) { (void)hipFree(op->jobs.front().d_jobs); op->jobs.erase(op->jobs.begin()); }
+        op->jobs.push_back(jl);
+        ++n_imported;
+    }
+    ++h->list_epoch;
+    return n_imported;
+}
+
 int dg_profile_enable(dg_handle* h, int on) {
     if (!h) return fail(DG_E_INVALID, "null handle");
     h->prof_stride = on > 0 ? on : 0;
@@ -1301,6 +1528,7 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
 int dg_set_option(dg_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
     const std::string k(key);
+    ++h->list_epoch;                     // whatever changes, captured loops are rebuilt on their next use
     if (k == "two_streams") {
         h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
@@ -1314,6 +1542,29 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "two_stream_min_rows") {
         h->two_stream_min_rows = atoi(value);
+        return DG_OK;
+    }
+    if (k == "graph_max_rows") {         // call shapes of at most this many latent rows replay a captured graph of the loop; 0 = never
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->graph_max_rows = atoi(value) > 0 ? atoi(value) : 0;
+        h->graph_broken = false;
+        drop_graphs(h);
+        free_workspace(h);               // the staging copy of the images is sized by this option
+        return DG_OK;
+    }
+    if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->latent_turn = atoi(value) != 0;
+        ++h->list_epoch;
+        return DG_OK;                    // job lists the other setting needs are built by the next prepare / call
+    }
+    if (k == "lin_groups_fwd" || k == "lin_groups_bwd") {
+        const int v = atoi(value);
+        if (v < 0 || v > 4096) return fail(DG_E_INVALID, "%s: 0 (auto) .. 4096", key);
+        (k == "lin_groups_fwd" ? h->lin_groups_fwd : h->lin_groups_bwd) = v;
+        ++h->list_epoch;
         return DG_OK;
     }
     if (k == "tail_pipe") {

@@ -73,6 +73,29 @@ struct GemmArgs {
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
 int gemm_lds_bytes(int family, int min_level);
 
+// ---- weight-stationary Linear kernels of the latent turn (dg_linear.hip) ------------------------
+// Out[n, unit*out_unit + c] = epi( sum_{k < 32*kch} A[n*a_rowstride + unit*a_unit + k] * W[unit*w_unit + c*w_rowstride + k] ),
+// c < 128.  Forward (tflib/ops/linear.py:129-142): unit = a 128-feature column tile of W^T [features][latent], kch = latent/32.
+// Backward: unit = one of the engine's fixed K slices of W [latent][features] (kch = slice/32), Out = the split-K partials
+// [n][slice][latent] that momentum_update_kernel adds in slice order.  Same fma chains as launch_gemm (bit-identical).
+struct LinArgs {
+    const float* A;
+    const float* W;
+    float* Out;
+    const float* bias;       // forward only
+    long long a_rowstride;   // floats per row of A
+    long long out_rowstride; // floats per row of Out
+    int w_rowstride;         // floats between consecutive output columns of W
+    int a_unit, w_unit, out_unit;   // float offsets per unit
+    int n_rows;
+    int units;               // column tiles (forward) / K slices (backward)
+    int groups;              // workgroups per unit; group g owns the 32-row blocks g, g + groups, ...
+    int kch;                 // 32-float K chunks per row: 2, 4 or 6 forward, 8 backward
+    int mode;                // EpiMode (EPI_BIAS_RELU / EPI_BIAS forward, EPI_STORE backward)
+};
+bool lin_stationary_supported(int kch, int mode);
+void launch_lin_stationary(const LinArgs& a, hipStream_t s);
+
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
 // dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.
 struct MnistTailArgs {

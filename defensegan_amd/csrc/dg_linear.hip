@@ -1,0 +1,176 @@
+// The "latent turn" of a projection step on gfx950 (MI355X): Linear backward (split-K partials of dz), then -- after the
+// momentum update (dg_small.hip) -- Linear forward + BiasAdd + ReLU.  Reference call sites: tflib/ops/linear.py:129-142 inside
+// the loop body of models/gan.py:409-437.
+//
+// Both are [rows x K] . [K x 128-column tile] products with a SHORT K (128 forward, one 256-wide slice backward), which
+// the position-batched kernel (dg_gemm.hip) runs as thousands of 4- / 8-chunk jobs whose start-up and write-out are a third
+// of each job.  Here the weights are STATIONARY: a workgroup keeps the fragments of its 128 output columns (forward: a
+// column tile of W^T; backward: one K slice of W for all 128 latent columns) in REGISTERS for its whole life -- 64 / 128
+// VGPRs per lane -- and streams 32-row blocks of the other operand through a double-buffered LDS image (full 128-B lines by
+// buffer_load ... lds, XOR-swizzled on the source side exactly as in dg_gemm.hip).  One barrier, one 16 / 32 KB block and
+// 64 / 128 MFMAs per wave and block; the next block's DMA is in flight for a whole block; the B operand is never staged
+// (LDS-DMA pieces per MFMA: 0.0625 against 0.19-0.25 for the small job shapes).
+//
+// Arithmetic: every output element is the same k-ordered fp32 fma chain as in dg_gemm.hip (chunks of 32 in ascending order,
+// inside a chunk the MFMA k-pairs (8kk + e, 8kk + 4 + e), e = 0..3, kk = 0..3) and the same epilogue expressions, so the
+// results are BIT-IDENTICAL to the generic kernel's (tests/test_gpu_variants.py) and, like them, independent of the batch a
+// row is in.  The backward keeps the engine's fixed K slices: slice sums are still added in slice order by the update.
+#include "dg_kernels.h"
+
+namespace dg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+
+__device__ __forceinline__ int lswz(int row) { return (row >> 1) & 7; }
+
+// KCH: 32-float K chunks per block row (forward: latent / 32; backward: slice width / 32)
+template <int KCH, int MODE>
+__global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_stationary_kernel(LinArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLK_BYTES = KCH * 4096;             // one 32-row block: [KCH chunks][32 rows][128 B]
+    char* const epi = smem + 2 * BLK_BYTES;           // [4 waves][32 x 32 floats] transposition tiles
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+
+    const int unit = (int)blockIdx.x % g.units;       // column tile (forward) / K slice (backward)
+    const int grp = (int)blockIdx.x / g.units;        // row group: blocks grp, grp + groups, ...
+    const int n_blocks = (g.n_rows + 31) >> 5;
+    const int n_my = grp < n_blocks ? (n_blocks - grp + g.groups - 1) / g.groups : 0;
+    if (n_my == 0) return;
+
+    // ---- streamed operand: rows of A, one 32-float chunk of a row = one 128-B line, 8 rows per DMA instruction; wave w
+    // stages rows 8w .. 8w+7 of every chunk.  LDS slot s of a row receives source chunk s ^ swz(row).
+    const float* const a_unit = g.A + (long long)unit * g.a_unit;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned sslot = (unsigned)(((lane & 7) ^ lswz(srow)) << 4);
+    auto stage = [&](int blk, char* dst) {
+        const int row0 = blk << 5;
+        int r = row0 + srow;
+        r = r < g.n_rows ? r : g.n_rows - 1;                       // ragged last block: clamp loads, mask stores
+        // descriptor based at the block's first row (64-bit), per-lane offset inside the block, chunk offset in an SGPR
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a_unit + (long long)row0 * g.a_rowstride), 0, 0x7ffffff0, 0x00020000);
+        const unsigned voff = (unsigned)(r - row0) * (unsigned)(g.a_rowstride * 4) + sslot;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DG_LDS_PTR(dst + c * 4096 + wave * 1024), 16, voff, c * 128, 0, 0);
+    };
+    stage(grp, smem);
+
+    // ---- stationary operand: this wave's 32 output columns x K, as MFMA B fragments (lane = column + 32 * k-half)
+    f32x4 wf[KCH][4];
+    {
+        const float* wp = g.W + (long long)unit * g.w_unit + (long long)(wave * 32 + frow) * g.w_rowstride + fh * 4;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) wf[c][kk] = *reinterpret_cast<const f32x4*>(wp + c * 32 + kk * 8);
+    }
+    const int er = lane >> 3, ec = (lane & 7) * 4;
+    const int ocol = unit * g.out_unit + wave * 32 + ec;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + ocol);
+    float* const tb = reinterpret_cast<float*>(epi + wave * 4096);
+    const int a_rd = frow * 128;
+    const int a_sw = lswz(frow);
+
+    for (int i = 0; i < n_my; ++i) {
+        const int blk = grp + i * g.groups;
+        // this wave's pieces of block i have landed once at most the 4 row stores of block i-1 (issued after them; VMEM
+        // operations retire in order) are outstanding; then the barrier: every wave's pieces are there, and every wave is
+        // done reading the other buffer
+        if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (i + 1 < n_my) stage(blk + g.groups, smem + ((i + 1) & 1) * BLK_BYTES);
+        const char* st = smem + (i & 1) * BLK_BYTES + a_rd;
+
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        f32x4 a[2][4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[0][kk] = *reinterpret_cast<const f32x4*>(st + (((kk * 2 + fh) ^ a_sw) << 4));
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            if (c + 1 < KCH) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    a[(c + 1) & 1][kk] = *reinterpret_cast<const f32x4*>(st + (c + 1) * 4096 + (((kk * 2 + fh) ^ a_sw) << 4));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][kk][e], wf[c][kk][e], acc, 0, 0, 0);
+        }
+
+        // ---- epilogue: transpose the 32 x 32 tile through this wave's LDS slice so that a lane owns 4 consecutive columns of
+        // one row (b128 stores), same expressions as dg_gemm.hip
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[e];
+        const int row0 = blk << 5;
+        f32x4 v[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the four reads are waited for once, not one by one
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            asm volatile("" : "+v"(v[p]));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float t = v[p][q] + bv[q];
+                if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
+                v[p][q] = t;
+            }
+            const int r = row0 + p * 8 + er;
+            if (r < g.n_rows) *reinterpret_cast<f32x4*>(g.Out + (long long)r * g.out_rowstride + ocol) = v[p];
+        }
+    }
+}
+
+template <int KCH, int MODE>
+void launch_km(const LinArgs& a, hipStream_t s) {
+    const int lds = 2 * KCH * 4096 + 4 * 4096;
+    static PerDeviceOnce attr;
+    if (attr.need())
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
+}
+
+template <int KCH>
+void launch_k(const LinArgs& a, hipStream_t s) {
+    if constexpr (KCH == 8) {
+        launch_km<KCH, EPI_STORE>(a, s);                     // backward: split-K partials
+    } else {
+        if (a.mode == EPI_BIAS) launch_km<KCH, EPI_BIAS>(a, s);      // forward with Batchnorm behind it
+        else launch_km<KCH, EPI_BIAS_RELU>(a, s);
+    }
+}
+
+}  // namespace
+
+bool lin_stationary_supported(int kch, int mode) {
+    return kch == 8 ? mode == EPI_STORE : ((kch == 2 || kch == 4 || kch == 6) && (mode == EPI_BIAS || mode == EPI_BIAS_RELU));
+}
+
+void launch_lin_stationary(const LinArgs& a, hipStream_t s) {
+    if (a.n_rows <= 0 || a.units <= 0 || a.groups <= 0) return;
+    switch (a.kch) {
+        case 2: launch_k<2>(a, s); break;
+        case 4: launch_k<4>(a, s); break;
+        case 6: launch_k<6>(a, s); break;
+        case 8: launch_k<8>(a, s); break;
+        default: break;
+    }
+}
+
+}  // namespace dg

@@ -1,6 +1,7 @@
 #include "dg_plan.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <functional>
 #include <map>
 #include <queue>
@@ -288,6 +289,43 @@ void order_for_xcd(std::vector<JobDesc>& jobs, int n_rows, double head_frac, int
     while (out < head)
         for (int x = 0; x < n_xcd && out < head; ++x)
             if (at[(size_t)x] < bucket[(size_t)x].size()) jobs[out++] = bucket[(size_t)x][at[(size_t)x]++];
+}
+
+void snake_order(std::vector<JobDesc>& jobs, int cus) {
+    if (cus <= 0) return;
+    for (size_t g0 = (size_t)cus; g0 < jobs.size(); g0 += 2 * (size_t)cus)
+        std::reverse(jobs.begin() + g0, jobs.begin() + std::min(jobs.size(), g0 + (size_t)cus));
+}
+
+std::string format_tune_record(const TuneRecord& r) {
+    char line[256];
+    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
+             r.xcd_head, r.n_jobs, r.measured_us);
+    return line;
+}
+
+bool parse_tune_record(const char** pp, TuneRecord* r) {
+    const char* p = *pp;
+    while (*p == '\n' || *p == ' ' || *p == '\r' || *p == '\t') ++p;
+    if (!*p) { *pp = p; return false; }
+    char name[32];
+    int used = 0;
+    TuneRecord t;
+    if (sscanf(p, "%31s %d %d %lf %d %d %lf %d %lf%n", name, &t.n_rows, &t.min_level, &t.slack, &t.snake, &t.xcd_order, &t.xcd_head,
+               &t.n_jobs, &t.measured_us, &used) != 9 || used <= 0)
+        return false;
+    t.op = name;
+    *r = t;
+    *pp = p + used;
+    return true;
+}
+
+std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus, int slots_per_cu, const TuneRecord& r,
+                                      const JobModel& model, double* predicted_us) {
+    std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, model, predicted_us, r.min_level);
+    if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
+    if (r.snake) snake_order(jobs, cus);
+    return jobs;
 }
 
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model) {

@@ -80,6 +80,29 @@ std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, in
 // keeps its longest-first order, which is what levels the end of the launch.  A pure permutation: results cannot change.
 void order_for_xcd(std::vector<JobDesc>& jobs, int n_rows, double head_frac, int n_xcd = 8);
 
+// ---- tuning records -------------------------------------------------------------------------------------------------
+// A job list is a pure function of (layer plan, row count, family, slots, starting level, cutting threshold, order variant):
+// these few numbers are what dg_export_tuning writes and dg_import_tuning reads (one text line per layer and row count), so
+// that another process reproduces the timed choice of this one exactly, without timing.
+struct TuneRecord {
+    std::string op;            // layer name ("F2", "B3", ...)
+    int n_rows = 0;
+    int min_level = 0;
+    double slack = 0.0;        // build_jobs' cutting threshold (<= 0: its ladder, 1e30: never cut)
+    int snake = 0;             // every other round of `cus` jobs reversed
+    int xcd_order = 0;         // order_for_xcd with head fraction xcd_head
+    double xcd_head = 0.0;
+    int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
+    double measured_us = 0.0;  // informational
+};
+std::string format_tune_record(const TuneRecord& r);                 // one line, '\n'-terminated
+// Parses the record at *p and advances *p behind it; false on a malformed record (nothing consumed) or at the end of the text.
+bool parse_tune_record(const char** p, TuneRecord* r);
+// The list the record describes (slots_per_cu = resident workgroups per CU at the record's level).
+std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus, int slots_per_cu, const TuneRecord& r,
+                                      const JobModel& model = JobModel(), double* predicted_us = nullptr);
+void snake_order(std::vector<JobDesc>& jobs, int cus);
+
 // Makespan (microseconds) of greedy list scheduling of `jobs` in order on `slots` servers of 1/slots of the chip each.
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model);
 

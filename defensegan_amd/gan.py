@@ -295,9 +295,59 @@ class DefenseGANBase(object):
         torch = _torch()
         dev = torch.device("cuda", self._device)
         B = int(batch_size or self.test_batch_size)
+        # DG_TUNING_CACHE=<file>: job-list choices made by an earlier process (the bench, before a profiler pass) are installed
+        # instead of being timed again, and this process's own choices are written back -- both runs then launch the same lists
+        cache = os.environ.get("DG_TUNING_CACHE")
+        if cache and os.path.exists(cache) and not getattr(self, "_tuning_cache_loaded", False):
+            self._tuning_cache_loaded = True
+            try:
+                with open(cache) as fh:
+                    self.import_tuning(fh.read())
+            except (_native.NativeError, OSError) as e:          # another configuration / device: tune afresh
+                if self.verbose:
+                    print("[defensegan_amd] %s ignored: %s" % (cache, e))
         with torch.cuda.device(dev):
             self._check(self._lib().dg_prepare(self._handle, B, int(self.rec_rr),
                                                     torch.cuda.current_stream(dev).cuda_stream))
+        if cache:
+            text = self.export_tuning()
+            try:
+                old = open(cache).read() if os.path.exists(cache) else None
+                if old != text:
+                    tmp = "%s.%d.tmp" % (cache, os.getpid())
+                    with open(tmp, "w") as fh:
+                        fh.write(text)
+                    os.replace(tmp, cache)
+            except OSError:
+                pass
+
+    # ------------------------------------------------------------------ tuning hand-over (dg_export_tuning / dg_import_tuning)
+    def export_tuning(self) -> str:
+        """The job-list choices of this handle as text (one line per GEMM layer and row count)."""
+        self._ensure_handle()
+        lib = self._lib()
+        need = int(lib.dg_export_tuning(self._handle, None, 0))
+        if need < 0:
+            self._check(need)
+        buf = C.create_string_buffer(need)
+        got = int(lib.dg_export_tuning(self._handle, C.cast(buf, C.c_void_p), need))
+        if got < 0:
+            self._check(got)
+        return buf.value.decode()
+
+    def import_tuning(self, text: str) -> int:
+        """Installs the choices of another handle's ``export_tuning`` (same architecture, options and CU count) without timing;
+        returns the number of lists installed."""
+        self._ensure_handle()
+        n = int(self._lib().dg_import_tuning(self._handle, text.encode()))
+        if n < 0:
+            self._check(n)
+        return n
+
+    def tuning_id(self) -> str:
+        """12 hex digits identifying WHICH job lists are installed (the measured durations are left out): two processes that
+        print the same id launch the same lists for every layer."""
+        return tuning_text_id(self.export_tuning())
 
     def reconstruct_dataset(self, splits, checkpoint_dir, batch_size=None, max_num=-1, test_again=False, seed=None):
         """Counterpart of ``reconstruct_dataset`` (gan.py:451-587) for in-memory splits.
@@ -447,6 +497,12 @@ class DefenseGANBase(object):
         if got < 0:
             self._check(int(got))
         return t[:got]
+
+
+def tuning_text_id(text: str) -> str:
+    import hashlib
+    lines = [ln.rsplit(" ", 1)[0] if i else ln for i, ln in enumerate(text.strip().splitlines())]     # drop measured_us
+    return hashlib.sha256("\n".join(sorted(lines[1:]) if len(lines) > 1 else lines).encode()).hexdigest()[:12]
 
 
 class ReconstructionLayer(object):

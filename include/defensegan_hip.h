@@ -120,6 +120,18 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
 int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R,
                  float* out_y, float* out_loss, float* out_dz, void* stream);
 
+/*
+ * The job list a GEMM layer runs with for a row count is chosen by timing candidates on first use (dg_prepare), so two
+ * processes can settle on different -- equally correct, bit-identical in their results -- lists.  dg_export_tuning writes the
+ * choices made so far as text (one line per layer and row count: starting level, cutting threshold, order variant) into
+ * buf and returns the bytes needed including the terminating NUL (call with buf = NULL to size); dg_import_tuning rebuilds
+ * exactly those lists in another handle of the same configuration without timing and returns the number of lists installed
+ * (>= 0) or a negative DG_E_* code.  Use: the ranks of a multi-GPU run import rank 0's text; a profiler pass imports the
+ * bench's (defensegan_amd/gan.py: export_tuning / import_tuning / the DG_TUNING_CACHE file).
+ */
+int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap);
+int dg_import_tuning(dg_handle* h, const char* text);
+
 /* Fills z [n_rows, latent] with the same N(0, std^2) draw dg_reconstruct uses for z0 == NULL
  * (std <= 0 selects sqrt(1/latent)). */
 int dg_init_latents(dg_handle* h, float* z, int64_t n_rows, uint64_t seed, int64_t first_row,
@@ -154,7 +166,13 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,
  *                      tf.train.exponential_decay(rec_lr, k, ceil(0.8 * rec_iters), 0.1, staircase=True) (base_model.py:186-192)
  *   "nsplit"           split-K factor of the Linear backward (default 16)
- *   "two_streams"      number of concurrent row groups (0/1 = off, 2..4); "two_stream_min_rows"
+ *   "two_streams"      number of concurrent row groups (0/1 = off, 2..8); "two_stream_min_rows"
+ *   "latent_turn"      1 (default): Linear backward / forward on the weight-stationary kernels (dg_linear.hip) where the shapes
+ *                      allow; 0: on the position-batched kernel like every other layer.  "lin_groups_fwd" / "lin_groups_bwd":
+ *                      their workgroups per column tile / K slice (0 = from the CU count)
+ *   "graph_max_rows"   call shapes of at most this many latent rows (default 1024) replay a captured hipGraph of the L-step loop
+ *                      instead of enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum);
+ *                      never while the caller's stream is itself capturing); 0 = always enqueue
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd_split"   CelebA forward tail (NET_DIM 64): workgroups of the role-split persistent kernel (default 512 = two per CU);
  *                      0 = the per-band kernel (celeba_tail_fwd16_kernel; same y and da6 bit for bit, the per-row loss to rounding)

@@ -102,6 +102,37 @@ double dgp2_order_for_xcd(void* h, int n_rows, double head_frac, int n_xcd, int 
     return dg::simulate_jobs(b.plan, b.jobs, b.family, slots, dg::JobModel());
 }
 double dgp2_predicted_us(void* h) { return static_cast<Batched*>(h)->predicted_us; }
+
+// ---- tuning records (dg_export_tuning / dg_import_tuning, dg_plan.h TuneRecord) ---------------------------------------
+// Builds the list of (row count, level, threshold, order variant) the way the engine's timing does, keeps it as the current
+// list and writes its record line into `line`; returns the list's length.
+int dgp2_make_recorded(void* h, const char* op, int n_rows, int cus, int slots_per_cu, int min_level, double slack, int snake,
+                       double xcd_head, char* line, int cap) {
+    Batched& b = *static_cast<Batched*>(h);
+    dg::TuneRecord r;
+    r.op = op; r.n_rows = n_rows; r.min_level = min_level; r.slack = slack; r.snake = snake;
+    r.xcd_order = xcd_head > 0.0; r.xcd_head = xcd_head;
+    b.jobs = dg::jobs_from_record(b.plan, b.family, cus, slots_per_cu, r, dg::JobModel(), &b.predicted_us);
+    r.n_jobs = (int)b.jobs.size();
+    r.measured_us = 123.456;
+    const std::string t = dg::format_tune_record(r);
+    if ((int)t.size() + 1 > cap) return -1;
+    std::memcpy(line, t.c_str(), t.size() + 1);
+    return r.n_jobs;
+}
+// Parses `text` (record lines), rebuilds the list of its record number `which` and compares it byte for byte with the
+// current list: 1 equal, 0 different, -1 malformed / no such record, -2 the record's job count does not match.
+int dgp2_rebuild_matches(void* h, const char* text, int which, int cus, int slots_per_cu) {
+    Batched& b = *static_cast<Batched*>(h);
+    const char* p = text;
+    dg::TuneRecord r;
+    for (int i = 0; i <= which; ++i)
+        if (!dg::parse_tune_record(&p, &r)) return -1;
+    const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(b.plan, b.family, cus, slots_per_cu, r);
+    if ((int)jobs.size() != r.n_jobs) return -2;
+    if (jobs.size() != b.jobs.size()) return 0;
+    return std::memcmp(jobs.data(), b.jobs.data(), jobs.size() * sizeof(dg::JobDesc)) == 0 ? 1 : 0;
+}
 void dgp2_jobs(void* h, int* out) {           // per job: cls, shape, n0, n_first, j_first, m_valid
     const Batched& b = *static_cast<Batched*>(h);
     for (size_t i = 0; i < b.jobs.size(); ++i) {

@@ -80,9 +80,12 @@ def _run(gan, x, z0):
 BITWISE = {
     "mnist": [{"tail_pipe": 0}, {"tail_pipe": 100}, {"two_streams": 2, "two_stream_min_rows": 64},
               {"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01, "jobs.min_level": 0}, {"jobs.min_level": 1},
-              {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300}],
+              {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300},
+              # the latent turn: position-batched kernel instead of the weight-stationary ones; other workgroup counts
+              {"latent_turn": 0}, {"lin_groups_fwd": 3, "lin_groups_bwd": 5}, {"lin_groups_fwd": 64, "lin_groups_bwd": 64}],
     "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
-               {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300}],
+               {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300},
+               {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}],
 }
 
 
@@ -105,6 +108,27 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
         got = _run(g2, x, z0)
         for k in ("rec", "idx", "loss", "z"):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+@pytest.mark.parametrize("arch,latent_dim,net_dim", [("mnist", 128, 64), ("mnist", 64, 64), ("celeba", 192, 64), ("mnist", 128, 128)])
+def test_latent_turn_kernels_reproduce_the_generic_gemm(arch, latent_dim, net_dim):
+    """dg_linear.hip (weights stationary in registers, rows streamed in 32-row blocks) against the position-batched kernel
+    (option latent_turn = 0) on ragged row counts: the same fma chains and epilogue expressions, so G(z), the loss and dL/dz
+    are BIT-identical.  latent_dim 64 / 192 exercise the 2- and 6-chunk forward instantiations (their backward and the
+    NET_DIM 128 backward stay on the position-batched kernel)."""
+    a = archs.make_arch(arch, latent_dim, net_dim)
+    g1, p = _make(arch, net_dim, latent_dim, R=1, L=1)
+    g0, _ = _make(arch, net_dim, latent_dim, R=1, L=1)
+    g0.set_option("latent_turn", 0)
+    rs = np.random.RandomState(3)
+    for n in (1, 5, 31, 32, 33, 97, 130, 517):
+        z = (rs.standard_normal((n, latent_dim)) * 0.15).astype(np.float32)
+        x = rs.uniform(a.in_lo, a.in_hi, size=(n,) + tuple(a.image_dim)).astype(np.float32)
+        got = [np.asarray(v) for v in g1.loss_grad(x, z)]
+        ref = [np.asarray(v) for v in g0.loss_grad(x, z)]
+        assert np.isfinite(ref[2]).all() and np.abs(ref[2]).max() > 0
+        for name, u, v in zip(("y", "loss", "dz"), got, ref):
+            assert np.array_equal(u, v), (n, name, np.abs(u.astype(np.float64) - v).max())
 
 
 @pytest.mark.parametrize("B,wgs", [(70, 512), (3, 512), (40, 100)])

@@ -38,6 +38,9 @@ def lib():
     l.dgp2_predicted_us.argtypes = [C.c_void_p]
     l.dgp2_jobs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp2_apply.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
+    l.dgp2_make_recorded.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                     C.c_char_p, C.c_int]
+    l.dgp2_rebuild_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
     return l
 
 
@@ -286,3 +289,48 @@ def test_xcd_locality_order_is_a_permutation_that_gives_each_xcd_one_row_range(l
     np.testing.assert_allclose(out, np.maximum(O.deconv2d(x, F, bias, 7), 0), rtol=1e-12, atol=1e-12)
     assert (touched == 1).all()
     lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_tuning_records_round_trip_to_the_same_job_lists(lib):
+    """dg_export_tuning / dg_import_tuning (include/defensegan_hip.h): a job list is a pure function of the few numbers of its
+    record (row count, starting level, cutting threshold, order variant), so the text one process exports rebuilds, in another,
+    exactly the list the first one timed and kept -- byte for byte, for every variant the timing offers."""
+    h, _ = build(lib, "deconv_bwd", 7, 7, 14, 14, 128, 64, 128)          # MNIST Generator.3 backward
+    b = lib.dgp2_build(h)
+    lines = []
+    variants = [(2560, 0, 1e30, 0, 0.0), (2560, 1, 0.97, 0, 0.0), (2560, 1, 1.04, 1, 0.0), (500, 2, 0.85, 1, 0.0),
+                (2560, 0, 0.0, 0, 0.0), (1280, 1, 1.0, 0, 0.5), (37, 2, 1.1, 0, 0.0)]
+    slots = {0: 2, 1: 3, 2: 5}
+    for n_rows, lvl, slack, snake, xhead in variants:
+        line = C.create_string_buffer(256)
+        n = lib.dgp2_make_recorded(b, b"B3", n_rows, 256, slots[lvl], lvl, slack, snake, xhead, line, 256)
+        assert n > 0
+        text = line.value.decode()
+        f = text.split()
+        assert f[0] == "B3" and int(f[1]) == n_rows and int(f[2]) == lvl and float(f[3]) == slack and int(f[7]) == n
+        lines.append(text)
+        # the record alone rebuilds the list that is current
+        assert lib.dgp2_rebuild_matches(b, text.encode(), 0, 256, slots[lvl]) == 1
+        # ... and the order variant is part of it (the record is not vacuous): the same record with the snake flag flipped
+        # describes another list whenever more than one round of 256 jobs exists
+        if n > 256:
+            f2 = list(f)
+            f2[4] = str(1 - snake)
+            assert lib.dgp2_rebuild_matches(b, (" ".join(f2) + "\n").encode(), 0, 256, slots[lvl]) == 0
+    # a text of several records: each is found by position; garbage is reported, not skipped
+    text = "".join(lines)
+    n_rows, lvl, slack, snake, xhead = variants[-1]
+    assert lib.dgp2_rebuild_matches(b, text.encode(), len(variants) - 1, 256, slots[lvl]) == 1
+    assert lib.dgp2_rebuild_matches(b, (text + "B3 what\n").encode(), len(variants), 256, 2) == -1
+    assert lib.dgp2_rebuild_matches(b, text.encode(), len(variants), 256, 2) == -1
+    lib.dgp2_free(b)
+    lib.dgp_free(h)
+
+
+def test_tuning_text_id_ignores_order_and_measured_durations():
+    from defensegan_amd.gan import tuning_text_id
+    head = "dgtune 1 arch 0 latent 128 net_dim 64 use_bn 0 nsplit 16 cus 256\n"
+    a = head + "F2 2560 1 0.97 0 0 0 2024 293.500\nB2 2560 1 1 0 0 0 1344 285.600\n"
+    b = head + "B2 2560 1 1 0 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
+    c = head + "B2 2560 1 1 1 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
+    assert tuning_text_id(a) == tuning_text_id(b) != tuning_text_id(c)
