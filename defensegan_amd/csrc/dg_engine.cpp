@@ -121,6 +121,9 @@ struct dg_handle {
     float* lin_w = nullptr;    // [latent][lin_out]   reference layout; K-contiguous operand of the backward
     float* lin_wt = nullptr;   // [lin_out][latent]   K-contiguous operand of the forward
     float* lin_b = nullptr;
+    float* lin_pack_fwd = nullptr; // lin_wt / lin_w in the MFMA fragment order of dg_linear.hip (dg_kernels.h lin_pack_index), or nullptr
+    float* lin_pack_bwd = nullptr;
+    std::vector<float> lin_w_host; // [latent][lin_out]: the packs are rebuilt when nsplit changes
     std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
     float* tail_pack = nullptr;        // last deconv's filters in MFMA fragment order (forward tail GEMM)
     float* tail_pack16 = nullptr;      // same, 16x16x4 fragments of the kh-aligned tiles (CelebA forward tail)
@@ -649,17 +652,58 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
 // F1 / B1 on the weight-stationary kernels (dg_linear.hip)?
 bool lin_stationary(const dg_handle* h, const GemmOp& op) {
     if (!h->latent_turn) return false;
-    if (&op == &h->F1) return h->lin_out % 128 == 0 && h->latent % 32 == 0 && dg::lin_stationary_supported(h->latent / 32, op.mode);
-    if (&op == &h->B1)
-        return h->latent == 128 && h->lin_out % (h->nsplit * 32) == 0 && dg::lin_stationary_supported(h->lin_out / h->nsplit / 32, op.mode);
+    if (&op == &h->F1) return h->lin_pack_fwd != nullptr && dg::lin_stationary_supported(h->latent / 32, op.mode);
+    if (&op == &h->B1) return h->lin_pack_bwd != nullptr && dg::lin_stationary_supported(h->lin_out / h->nsplit / 32, op.mode);
     return false;
+}
+
+// Fragment-order copies of the Linear weights for dg_linear.hip (forward: 128-feature column tiles of W^T; backward: the
+// nsplit K slices of W, all 128 latent columns each), built from the host copy kept by dg_set_weights.
+int build_lin_packs(dg_handle* h) {
+    auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    HIP_TRY(hipDeviceSynchronize());
+    fr(h->lin_pack_fwd); fr(h->lin_pack_bwd);
+    ++h->list_epoch;
+    if (h->lin_w_host.empty()) return DG_OK;
+    const int K = h->latent, F = h->lin_out;
+    const float* W = h->lin_w_host.data();               // [K][F]
+    std::vector<float> pk((size_t)K * F);
+    if (F % 128 == 0 && K % 32 == 0 && dg::lin_stationary_supported(K / 32, dg::EPI_BIAS_RELU)) {
+        const int kch = K / 32;
+        for (int u = 0; u < F / 128; ++u)
+            for (int w = 0; w < 4; ++w)
+                for (int c = 0; c < kch; ++c)
+                    for (int kk = 0; kk < 4; ++kk)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int f = u * 128 + w * 32 + (lane & 31), k = c * 32 + (kk * 2 + (lane >> 5)) * 4 + e;
+                                pk[(size_t)dg::lin_pack_index(u, w, kch, c, kk, lane, e)] = W[(size_t)k * F + f];      // W^T[f][k]
+                            }
+        HIP_TRY(hipMalloc(&h->lin_pack_fwd, pk.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->lin_pack_fwd, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (K == 128 && F % (h->nsplit * 32) == 0 && dg::lin_stationary_supported(F / h->nsplit / 32, dg::EPI_STORE)) {
+        const int ks = F / h->nsplit, kch = ks / 32;
+        for (int s = 0; s < h->nsplit; ++s)
+            for (int w = 0; w < 4; ++w)
+                for (int c = 0; c < kch; ++c)
+                    for (int kk = 0; kk < 4; ++kk)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 4; ++e) {
+                                const int d = w * 32 + (lane & 31), f = s * ks + c * 32 + (kk * 2 + (lane >> 5)) * 4 + e;
+                                pk[(size_t)dg::lin_pack_index(s, w, kch, c, kk, lane, e)] = W[(size_t)d * F + f];
+                            }
+        HIP_TRY(hipMalloc(&h->lin_pack_bwd, pk.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->lin_pack_bwd, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return DG_OK;
 }
 
 int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
     const bool fwd = &op == &h->F1;
     dg::LinArgs a;
     a.A = A;
-    a.W = op.W;
+    a.Wp = fwd ? h->lin_pack_fwd : h->lin_pack_bwd;
     a.Out = Out;
     a.bias = op.bias;
     a.n_rows = n_rows;
@@ -668,7 +712,6 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
     int want;
     if (fwd) {
         a.a_rowstride = h->latent; a.a_unit = 0;
-        a.w_rowstride = h->latent; a.w_unit = 128 * h->latent;
         a.out_rowstride = h->lin_out; a.out_unit = 128;
         a.units = h->lin_out / 128;
         a.kch = h->latent / 32;
@@ -676,13 +719,15 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
     } else {
         const int ks = h->lin_out / h->nsplit;
         a.a_rowstride = h->lin_out; a.a_unit = ks;
-        a.w_rowstride = h->lin_out; a.w_unit = ks;
         a.out_rowstride = (long long)h->nsplit * h->latent; a.out_unit = h->latent;
         a.units = h->nsplit;
         a.kch = ks / 32;
         want = h->lin_groups_bwd > 0 ? h->lin_groups_bwd : std::max(1, h->cu_count / a.units);         // one workgroup per CU
     }
     a.groups = std::min(n_blocks, want);
+#ifdef DG_MEASURE
+    a.trace = (h->d_job_trace && op.name == h->job_trace_op && a.units * a.groups * 2 <= kJobTraceCap) ? h->d_job_trace : nullptr;
+#endif
     char sym[64];
     snprintf(sym, sizeof sym, "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
     {
@@ -1115,7 +1160,7 @@ int dg_destroy(dg_handle* h) {
     free_workspace(h);
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
-    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
+    fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->lin_pack_fwd); fr(h->lin_pack_bwd); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
     if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
     if (h->d_job_trace) (void)hipFree(h->d_job_trace);
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
@@ -1177,6 +1222,9 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
             for (int f = 0; f < h->lin_out; ++f) t[(size_t)f * h->latent + d] = host[(size_t)d * h->lin_out + f];
         HIP_TRY(hipMemcpy(h->lin_w, host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->lin_wt, t.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+        h->lin_w_host = host;
+        const int rcp = build_lin_packs(h);
+        if (rcp) return rcp;
         h->have[nm] = true;
         return DG_OK;
     }
@@ -1648,6 +1696,8 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         HIP_TRY(hipDeviceSynchronize());
         h->nsplit = v;
         free_workspace(h);
+        const int rcp = build_lin_packs(h);
+        if (rcp) return rcp;
         return rebuild_plans(h);
     }
     return fail(DG_E_INVALID, "unknown option '%s'", key);

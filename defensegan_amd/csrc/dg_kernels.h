@@ -74,26 +74,37 @@ void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
 int gemm_lds_bytes(int family, int min_level);
 
 // ---- weight-stationary Linear kernels of the latent turn (dg_linear.hip) ------------------------
-// Out[n, unit*out_unit + c] = epi( sum_{k < 32*kch} A[n*a_rowstride + unit*a_unit + k] * W[unit*w_unit + c*w_rowstride + k] ),
+// Out[n, unit*out_unit + c] = epi( sum_{k < 32*kch} A[n*a_rowstride + unit*a_unit + k] * Wunit[c][k] ),
 // c < 128.  Forward (tflib/ops/linear.py:129-142): unit = a 128-feature column tile of W^T [features][latent], kch = latent/32.
 // Backward: unit = one of the engine's fixed K slices of W [latent][features] (kch = slice/32), Out = the split-K partials
 // [n][slice][latent] that momentum_update_kernel adds in slice order.  Same fma chains as launch_gemm (bit-identical).
+// The weights arrive in MFMA FRAGMENT ORDER (lin_pack_index, built once per weight upload by dg_engine.cpp): the registers a
+// lane keeps for the workgroup's life are consecutive 16-byte pieces of one array, so the 64 / 128 KB a workgroup loads are
+// fully coalesced 1 KB runs (the reference layouts would be 32 partial lines per load instruction, 16 KB apart).
 struct LinArgs {
     const float* A;
-    const float* W;
+    const float* Wp;         // [units][4 waves][kch][4 k-steps][64 lanes][4]: lane = column (lane & 31) + 32 * k-half
     float* Out;
     const float* bias;       // forward only
     long long a_rowstride;   // floats per row of A
     long long out_rowstride; // floats per row of Out
-    int w_rowstride;         // floats between consecutive output columns of W
-    int a_unit, w_unit, out_unit;   // float offsets per unit
+    int a_unit, out_unit;    // float offsets per unit
     int n_rows;
     int units;               // column tiles (forward) / K slices (backward)
     int groups;              // workgroups per unit; group g owns the 32-row blocks g, g + groups, ...
     int kch;                 // 32-float K chunks per row: 2, 4 or 6 forward, 8 backward
     int mode;                // EpiMode (EPI_BIAS_RELU / EPI_BIAS forward, EPI_STORE backward)
+#ifdef DG_MEASURE
+    long long* trace;        // optional [grid][8] shader-clock stamps of every workgroup: start, first block ready, first block
+                             // multiplied, first block stored, end, HW_ID, blocks, -
+#endif
 };
 bool lin_stationary_supported(int kch, int mode);
+// float index inside Wp of element e of the fragment (unit, wave, chunk c, k-step kk, lane): the weight of output column
+// wave*32 + (lane & 31) of the unit at k = c*32 + (kk*2 + (lane >> 5))*4 + e
+__host__ __device__ inline long long lin_pack_index(int unit, int wave, int kch, int c, int kk, int lane, int e) {
+    return ((((long long)(unit * 4 + wave) * kch + c) * 4 + kk) * 64 + lane) * 4 + e;
+}
 void launch_lin_stationary(const LinArgs& a, hipStream_t s);
 
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------

@@ -6,7 +6,7 @@
 // the position-batched kernel (dg_gemm.hip) runs as thousands of 4- / 8-chunk jobs whose start-up and write-out are a third
 // of each job.  Here the weights are STATIONARY: a workgroup keeps the fragments of its 128 output columns (forward: a
 // column tile of W^T; backward: one K slice of W for all 128 latent columns) in REGISTERS for its whole life -- 64 / 128
-// VGPRs per lane -- and streams 32-row blocks of the other operand through a double-buffered LDS image (full 128-B lines by
+// VGPRs per lane, loaded from a fragment-order copy of the weights in fully coalesced runs -- and streams 32-row blocks of the other operand through a double-buffered LDS image (full 128-B lines by
 // buffer_load ... lds, XOR-swizzled on the source side exactly as in dg_gemm.hip).  One barrier, one 16 / 32 KB block and
 // 64 / 128 MFMAs per wave and block; the next block's DMA is in flight for a whole block; the B operand is never staged
 // (LDS-DMA pieces per MFMA: 0.0625 against 0.19-0.25 for the small job shapes).
@@ -44,6 +44,11 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
     const int n_blocks = (g.n_rows + 31) >> 5;
     const int n_my = grp < n_blocks ? (n_blocks - grp + g.groups - 1) / g.groups : 0;
     if (n_my == 0) return;
+#ifdef DG_MEASURE
+    long long tr[4] = {0, 0, 0, 0};
+    const bool tron = g.trace != nullptr && tid == 0;
+    if (tron) tr[0] = (long long)__builtin_readcyclecounter();
+#endif
 
     // ---- streamed operand: rows of A, one 32-float chunk of a row = one 128-B line, 8 rows per DMA instruction; wave w
     // stages rows 8w .. 8w+7 of every chunk.  LDS slot s of a row receives source chunk s ^ swz(row).
@@ -63,64 +68,46 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DG_LDS_PTR(dst + c * 4096 + wave * 1024), 16, voff, c * 128, 0, 0);
     };
     stage(grp, smem);
+    if (n_my > 1) stage(grp + g.groups, smem + BLK_BYTES);       // both buffers are free: the second block rides with the weights
 
     // ---- stationary operand: this wave's 32 output columns x K, as MFMA B fragments (lane = column + 32 * k-half)
     f32x4 wf[KCH][4];
     {
-        const float* wp = g.W + (long long)unit * g.w_unit + (long long)(wave * 32 + frow) * g.w_rowstride + fh * 4;
+        const float* wp = g.Wp + lin_pack_index(unit, wave, KCH, 0, 0, lane, 0);
 #pragma unroll
         for (int c = 0; c < KCH; ++c)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) wf[c][kk] = *reinterpret_cast<const f32x4*>(wp + c * 32 + kk * 8);
+            for (int kk = 0; kk < 4; ++kk) wf[c][kk] = *reinterpret_cast<const f32x4*>(wp + (c * 4 + kk) * 256);
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const int ocol = unit * g.out_unit + wave * 32 + ec;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + ocol);
+    // the bias is the load issued last: once it is there everything before it is (loads retire in order) -- told to the
+    // compiler here so that it does not wait for "outstanding" loads again inside the loop
+    asm volatile("" : "+v"(bv));
     float* const tb = reinterpret_cast<float*>(epi + wave * 4096);
     const int a_rd = frow * 128;
     const int a_sw = lswz(frow);
 
-    for (int i = 0; i < n_my; ++i) {
-        const int blk = grp + i * g.groups;
-        // this wave's pieces of block i have landed once at most the 4 row stores of block i-1 (issued after them; VMEM
-        // operations retire in order) are outstanding; then the barrier: every wave's pieces are there, and every wave is
-        // done reading the other buffer
-        if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (i + 1 < n_my) stage(blk + g.groups, smem + ((i + 1) & 1) * BLK_BYTES);
-        const char* st = smem + (i & 1) * BLK_BYTES + a_rd;
-
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        f32x4 a[2][4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) a[0][kk] = *reinterpret_cast<const f32x4*>(st + (((kk * 2 + fh) ^ a_sw) << 4));
-#pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            if (c + 1 < KCH) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    a[(c + 1) & 1][kk] = *reinterpret_cast<const f32x4*>(st + (c + 1) * 4096 + (((kk * 2 + fh) ^ a_sw) << 4));
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][kk][e], wf[c][kk][e], acc, 0, 0, 0);
-        }
-
-        // ---- epilogue: transpose the 32 x 32 tile through this wave's LDS slice so that a lane owns 4 consecutive columns of
-        // one row (b128 stores), same expressions as dg_gemm.hip
+    // block 0 and the weights are there; every wave's pieces of it too
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ---- write-out of a finished 32 x 32 tile, in three pieces that ride INSIDE the next block's MFMA stream (a wave that wrote
+    // its tile out between two blocks left the matrix pipe idle for a fifth of a block, and two workgroups sharing a CU ran
+    // that phase in lock step): transpose through this wave's LDS slice so that a lane owns 4 consecutive columns of one row,
+    // then b128 stores; same expressions as dg_gemm.hip
+    auto out_write = [&](const f32x16& acc) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[e];
-        const int row0 = blk << 5;
-        f32x4 v[4];
+    };
+    auto out_read = [&](f32x4 (&v)[4]) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) v[p] = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the four reads are waited for once, not one by one
+    };
+    auto out_store = [&](f32x4 (&v)[4], int blk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (the next chunk's fragment reads were issued before these)
+        const int row0 = blk << 5;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             asm volatile("" : "+v"(v[p]));
@@ -133,7 +120,71 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
             const int r = row0 + p * 8 + er;
             if (r < g.n_rows) *reinterpret_cast<f32x4*>(g.Out + (long long)r * g.out_rowstride + ocol) = v[p];
         }
+    };
+
+    f32x16 done;                       // the previous block's tile, written out while this block multiplies
+    for (int i = 0; i < n_my; ++i) {
+        const int blk = grp + i * g.groups;
+#ifdef DG_MEASURE
+        if (tron && i == 0) tr[1] = (long long)__builtin_readcyclecounter();
+#endif
+        if (i > 0 && i + 1 < n_my) stage(blk + g.groups, smem + ((i + 1) & 1) * BLK_BYTES);     // in flight for the whole block
+        const char* st = smem + (i & 1) * BLK_BYTES + a_rd;
+
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        f32x4 a[2][4];
+        f32x4 v[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a[0][kk] = *reinterpret_cast<const f32x4*>(st + (((kk * 2 + fh) ^ a_sw) << 4));
+        if (i > 0) out_write(done);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            if (c + 1 < KCH) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    a[(c + 1) & 1][kk] = *reinterpret_cast<const f32x4*>(st + (c + 1) * 4096 + (((kk * 2 + fh) ^ a_sw) << 4));
+            }
+            if (c == 0 && i > 0) out_read(v);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][kk][e], wf[c][kk][e], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c == (KCH > 2 ? 1 : 0) && i > 0) out_store(v, blk - g.groups);
+        }
+        done = acc;
+#ifdef DG_MEASURE
+        if (tron && i == 0) tr[2] = (long long)__builtin_readcyclecounter();
+        if (tron && i == 1) tr[3] = (long long)__builtin_readcyclecounter();
+#endif
+        if (i + 1 < n_my) {
+            // this wave's pieces of block i+1 have landed once at most the 4 row stores of block i-1 (issued after them, inside
+            // this block's stream; VMEM operations retire in order) are outstanding; then the barrier: every wave's pieces are
+            // there, and every wave is done reading the buffer the block after that will be staged into
+            if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
     }
+    {
+        f32x4 v[4];
+        out_write(done);
+        out_read(v);
+        out_store(v, grp + (n_my - 1) * g.groups);
+    }
+#ifdef DG_MEASURE
+    if (tron) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long* t = g.trace + (long long)blockIdx.x * 8;
+        t[0] = tr[0]; t[1] = tr[1]; t[2] = tr[2]; t[3] = tr[3]; t[4] = (long long)__builtin_readcyclecounter(); t[5] = hwid; t[6] = n_my; t[7] = xcc & 15;
+    }
+#endif
 }
 
 template <int KCH, int MODE>
