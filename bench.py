@@ -58,24 +58,32 @@ def build_id():
     return _b.code_digest()[:12]
 
 
-def traffic_for(workload, kernel, B, R):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/pmc_traffic.py: FETCH_SIZE doubled per
-    the gfx950 correction + WRITE_SIZE, separate --pmc runs).  PMC counters cannot be read from inside this process, so
-    the figure comes from a file -- and is quoted ONLY when that file was collected on exactly this build of the kernels
-    (its "build" field equals build_id()) and on this row count; otherwise null."""
+def traffic_for(workload, layers, B, R, tuning_id=None):
+    """HBM-side bytes per launch of the LAYERS that ran as the dominant kernel symbol, from the committed rocprofv3 PMC passes
+    (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate --pmc runs, rows keyed by layer
+    through the fixed launch order of a GD iteration).  PMC counters cannot be read from inside this process, so the figure
+    comes from a file -- and is quoted ONLY when that file was collected on exactly this build of the kernels (its "build"
+    equals build_id()), on this row count, and -- the job list of a layer being a timed choice -- with the SAME job lists
+    (its "tuning_id" equals this process's, tools/collect_profiles.sh shares them through DG_TUNING_CACHE); otherwise null.
+    The value is the mean over the named layers (what `achieved` averages over)."""
     path = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     key = "mnist" if workload in ("mnist", "fmnist") else workload
-    if kernel is None or not os.path.exists(path) or B * R != {"mnist": 2560, "celeba": 1280}.get(key, -1):
+    if not layers or not os.path.exists(path) or B * R != {"mnist": 2560, "celeba": 1280}.get(key, -1):
         return None, None
     with open(path) as fh:
         doc = json.load(fh)
-    # one build id per workload ("builds"): the two sets may have been collected at different times
-    if doc.get("builds", {}).get(key, doc.get("build")) != build_id():
+    if doc.get("builds", {}).get(key) != build_id():
         return None, None
-    return doc.get(key, {}).get(kernel, {}).get("bytes_per_launch"), "profiles/" + TRAFFIC_FILE
+    if tuning_id is not None and doc.get("tuning_ids", {}).get(key) != tuning_id:
+        return None, None
+    rows = doc.get(key, {}).get("by_layer", {})
+    vals = [rows[l]["bytes_per_launch"] for l in layers if l in rows]
+    if len(vals) != len(layers):
+        return None, None
+    return int(sum(vals) / len(vals)), "profiles/" + TRAFFIC_FILE
 
 
-TRAFFIC_FILE = "r03_pmc_traffic.json"
+TRAFFIC_FILE = "r04_pmc_traffic.json"
 
 
 def make_inputs(gan, a, B, rank=0, first_image=0):
@@ -91,50 +99,59 @@ def make_inputs(gan, a, B, rank=0, first_image=0):
     return torch.clamp(x + 0.3 * torch.sign(noise), a.in_lo, a.in_hi).contiguous()
 
 
-def cpu_baseline(arch, params, x_np, R, L, budget_s=12.0):
-    """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed
-    here) on this box's host cores, bounded sample, scaled to images/s at the full L."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
+    """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed here) on this box's host
+    cores.  The thread count is probed on 2-step runs (oversubscribing these small convolutions is slower than using fewer
+    threads); then ONE batch of 16 images runs the FULL L steps at the best thread count -- a measured number, not a short
+    sample scaled by (2L-1) -- unless the probe predicts more than `budget_s` seconds, in which case the batch shrinks to 8 / 4
+    images before the step count does (and the sample line says what was done)."""
     from oracle import torch_ref as T          # checker / baseline only -- never on the product path
     ncpu = os.cpu_count() or 1
     gen = T.TorchGenerator(params, arch)
-    nimg = min(16, len(x_np))
     a = archs.make_arch(arch)
+    nimg = min(16, len(x_np))
     z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
-    Ls = 2
-    # oversubscribing small convolutions is slower than using fewer threads: probe a few thread counts
     best = None
     for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(th)
         T.reconstruct(params, x_np[:nimg], z0, R, 1, arch=arch, gen=gen)      # warm-up
         t0 = time.perf_counter()
-        T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
+        T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
         probe = time.perf_counter() - t0
         if best is None or probe < best[0]:
             best = (probe, th)
         if probe > 20:
             break
-    probe, cores = best
-    torch.set_num_threads(cores)
-    per_pass = probe / (2 * Ls - 1)
-    Ls = int(max(3, min(L, (budget_s / max(per_pass, 1e-6) + 1) // 2)))
-    # fast host: repeat the 16-image batch (it stays cache resident; bigger batches measured slower per image) while the
-    # measured time stays inside the budget -- the 2-step probe underestimates long runs, so this is decided as it goes
-    reps = 0
+    probe, threads = best
+    torch.set_num_threads(threads)
+    per_pass = probe / 3.0                       # 2 steps = 3 passes over nimg images
+    Ls, n_run = L, nimg
+    while n_run > 4 and per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
+        n_run //= 2
+    if per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
+        Ls = int(max(3, (budget_s / (per_pass * n_run / float(nimg)) + 1) // 2))
     t0 = time.perf_counter()
-    while True:
-        T.reconstruct(params, x_np[:nimg], z0, R, Ls, arch=arch, gen=gen)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if Ls < L or reps >= 8 or dt + dt / reps > 2.0 * budget_s:
-            break
-    t_full = dt / reps * (2 * L - 1) / (2 * Ls - 1)                            # work is linear in (2L-1) passes
-    nimg_total = nimg * reps
-    return {"value": nimg / t_full, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images (batches of %d) x R=%d x L=%d (torch-CPU autograd restatement, %d threads, %.1f s), "
-                      "scaled by (2L-1) to L=%d" % (nimg_total, nimg, R, Ls, cores, dt, L)}
+    T.reconstruct(params, x_np[:n_run], z0[:n_run * R], R, Ls, arch=arch, gen=gen)
+    dt = time.perf_counter() - t0
+    t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # == dt when the full L ran
+    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads of %d host cores, %.1f s measured%s" % (
+        n_run, R, Ls, threads, ncpu, dt, "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
+    return {"value": n_run / t_full, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": ncpu,
+            "cpu_model": _cpu_model(), "kind": "port", "sample": sample}
 
 
-def roofline_from_profile(prof, workload, B, R, path_tflops):
+def roofline_from_profile(prof, workload, B, R, path_tflops, tuning_id=None):
     """Per-layer rows + the roofline object of the dominant kernel symbol from the engine's event profile.  Profile
     entries are "<layer>@<kernel symbol>": per-layer rows for the breakdown, per-symbol groups (what rocprofv3 --stats
     aggregates) for the roofline."""
@@ -156,10 +173,12 @@ def roofline_from_profile(prof, workload, B, R, path_tflops):
         dom = {"kernel": sym, "avg_us": round(g["ms"] / g["launches"] * 1e3, 2),
                "flop_per_launch": g["flops"] / g["launches"],
                "tflops": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2)}
-    traffic, traffic_src = traffic_for(workload, dom["kernel"] if dom else None, B, R)
+    dom_layers = [k["name"] for k in kernels if dom and k["kernel"] == dom["kernel"]]
+    traffic, traffic_src = traffic_for(workload, dom_layers, B, R, tuning_id)
     roofline = {
         "bound": "mfma",
         "kernel": dom["kernel"] if dom else None,
+        "layers": dom_layers,
         "avg_launch_us": dom["avg_us"] if dom else None,
         "flop_per_launch": dom["flop_per_launch"] if dom else None,
         "achieved": dom["tflops"] if dom else round(path_tflops, 2),
@@ -314,9 +333,27 @@ def main():
             return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
         units_per_step = world * B
 
-    gan.prepare(B)          # workspace + timed job lists: outside the hot call (dg_prepare); the steps below only enqueue
-    if args.strong and (e0 - s0) % B:
-        gan.prepare((e0 - s0) % B)        # the ragged last projection batch of this rank's shard
+    # workspace + timed job lists: outside the hot call (dg_prepare); the steps below only enqueue.  With several ranks, rank 0
+    # times the candidates and every other rank installs ITS choices (dg_export_tuning -> broadcast -> dg_import_tuning): all
+    # ranks launch the same job lists, and the line below names them (tuning_id)
+    shapes = [B] + ([(e0 - s0) % B] if args.strong and (e0 - s0) % B else [])      # + the ragged last batch of this rank's shard
+    if distributed and world > 1:
+        if rank == 0:
+            for b in shapes:
+                gan.prepare(b)
+            payload = torch.tensor(list(gan.export_tuning().encode()), dtype=torch.uint8, device=dev)
+            n_bytes = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+        else:
+            n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.broadcast(n_bytes, 0)
+        if rank != 0:
+            payload = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(payload, 0)
+        if rank != 0:
+            gan.import_tuning(bytes(payload.cpu().tolist()).decode())
+    for b in shapes:
+        gan.prepare(b)
+    tuning_id = gan.tuning_id()
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -332,10 +369,15 @@ def main():
         dist.all_gather(gathered, msg)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank_ms, rank_tuning = [dt / args.steps * 1e3], [tuning_id]
     if distributed:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own time and job-list id (12 hex digits = 6 bytes), then the MAX over ranks is the reported time
+        mine = torch.tensor([dt] + [float(b) for b in bytes.fromhex(tuning_id)], dtype=torch.float64, device=dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(t[0].item()) / args.steps * 1e3 for t in allr]
+        rank_tuning = [bytes(int(v) for v in t[1:].tolist()).hex() for t in allr]
+        dt = max(float(t[0].item()) for t in allr)
 
     # ---- untimed: one more step with every kernel of every GD iteration bracketed by hipEvents (rank 0 reports)
     prof = []
@@ -355,7 +397,7 @@ def main():
         value = units_per_step * args.steps / dt
         flop_img = archs.flop_per_image(a, R, max(L, 1))
         path_tflops = value * flop_img / 1e12 / world           # per GPU
-        kernels, roofline = roofline_from_profile(prof, args.workload + ("_bn" if args.use_bn else ""), B, R, path_tflops)
+        kernels, roofline = roofline_from_profile(prof, args.workload + ("_bn" if args.use_bn else ""), B, R, path_tflops, tuning_id)
         # wall time of the ONE untimed step that carried the stream markers: its kernels' durations (consecutive launches share
         # a marker) add up to it; it is longer than a timed step by what ~8 markers per GD iteration cost (~3 us each)
         roofline["profiled_step_ms"] = round(profiled_step_ms, 3) if profiled_step_ms is not None else None
@@ -375,6 +417,10 @@ def main():
             "config": {"workload": wl, "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0,
                        "parallelism": "shard%d" % world},
             "build": build_id(),
+            # which job lists ran (a timed choice per layer and row count; identical ids = identical lists on every rank)
+            "tuning_id": tuning_id, "tuning_id_per_rank": rank_tuning,
+            "ranks": dist.get_world_size() if distributed else 1,     # ranks the process group (RCCL) actually holds
+            "ms_per_step_per_rank": [round(v, 3) for v in per_rank_ms],
             "roofline": roofline,
             "kernels": kernels,
         }

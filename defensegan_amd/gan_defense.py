@@ -36,7 +36,7 @@ def _np(a):
 def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_images, test_labels,
                    batch_size: int, rec_rr: int = 1, compute_diffs: bool = True, seed: int = 11241990,
                    first_image: int = 0, same_init_z: Optional[np.ndarray] = None,
-                   verbose: bool = False):
+                   verbose: bool = False, as_tensors: bool = False):
     """Accuracy of ``classifier(reconstruct(x))`` over ``test_images`` + reconstruction errors.
 
     reconstruct : ``f(images, z_init_val=None, seed=..., first_row=...) -> reconstructions`` or None
@@ -45,15 +45,27 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
     Returns ``(correct_count, n, roc_info)`` with ``roc_info = [labels, preds, diffs]``;
     ``diffs[i] = mean((x_i - rec_i)^2)`` (diff_op of whitebox.py:218 / blackbox.py:571-572).
     Accuracy = correct_count / n (gan_defense.py:166) -- kept as a count so shards can be summed.
+
+    With a device classifier (network_builder.MLP.eval_batch) the per-batch predictions, differences and correct counts stay
+    on the device and no batch waits for the stream: the host enqueues the whole evaluation and reads the results back once
+    at the end (the reference fetches ``acc_value / cur_preds / diff_op`` every batch, gan_defense.py:132-160).  ``as_tensors``
+    returns ``roc_info`` as tensors (labels / preds int32, diffs float32, on the classifier's device) for the sharded driver.
     """
     n = len(test_images)
     labels = _np(test_labels)
     if labels.ndim > 1:
         labels = labels.argmax(axis=-1)
     nb_batches = int(math.ceil(float(n) / batch_size))
-    preds: List[np.ndarray] = []
-    diffs: List[np.ndarray] = []
+    on_device = hasattr(classifier, "eval_batch")
+    preds: List = []
+    diffs: List = []
+    counts: List = []
     correct = 0
+    labels_dev = None
+    if on_device and n:
+        import torch
+        classifier._ensure()
+        labels_dev = torch.from_numpy(np.ascontiguousarray(labels.astype(np.int32))).to(torch.device("cuda", classifier._device))
     for batch in range(nb_batches):
         start = batch * batch_size
         end = min(n, start + batch_size)          # last batch may be smaller (gan_defense.py:124-130)
@@ -65,14 +77,14 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
             rec = reconstruct(x, seed=seed, first_row=(first_image + start) * rec_rr, **kw)
         else:
             rec = x
-        if hasattr(classifier, "eval_batch"):
-            # network_builder.MLP: classifier forward, argmax, correct count and diff_op in one device pass
-            # (dg_eval_batch); only [B] predictions / differences come back
-            ok, p_dev, d_dev = classifier.eval_batch(rec, x if compute_diffs else None, labels[start:end].astype(np.int32))
-            correct += ok
-            preds.append(_np(p_dev).astype(np.int64))
+        if on_device:
+            # network_builder.MLP: classifier forward, argmax, correct count and diff_op in one device pass (dg_eval_batch);
+            # [B] predictions / differences and the count stay on the device
+            c_dev, p_dev, d_dev = classifier.eval_batch(rec, x if compute_diffs else None, labels_dev[start:end], sync=False)
+            counts.append(c_dev)
+            preds.append(p_dev)
             if compute_diffs:
-                diffs.append(_np(d_dev).astype(np.float32))
+                diffs.append(d_dev)
         else:
             out = _np(classifier(rec))
             p = out.argmax(axis=-1) if out.ndim > 1 else out.astype(np.int64)
@@ -83,8 +95,20 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
                 diffs.append(((xr - rr) ** 2).mean(axis=1).astype(np.float32))
         if verbose:
             print("[#] Eval batch {}/{}".format(batch, nb_batches))
+    if on_device and n:
+        import torch
+        preds_t = torch.cat(preds)
+        diffs_t = torch.cat(diffs) if diffs else torch.zeros(0, dtype=torch.float32, device=preds_t.device)
+        correct = int(torch.cat(counts).sum().item())          # the one wait of the evaluation
+        if as_tensors:
+            return correct, n, [labels_dev, preds_t, diffs_t]
+        return correct, n, [labels.astype(np.int64), preds_t.cpu().numpy().astype(np.int64), diffs_t.cpu().numpy().astype(np.float32)]
     preds_all = np.concatenate(preds) if preds else np.zeros(0, np.int64)
     diffs_all = np.concatenate(diffs) if diffs else np.zeros(0, np.float32)
+    if as_tensors:
+        import torch
+        return correct, n, [torch.from_numpy(labels.astype(np.int32)), torch.from_numpy(preds_all.astype(np.int32)),
+                            torch.from_numpy(diffs_all.astype(np.float32))]
     return correct, n, [labels.astype(np.int64), preds_all, diffs_all]
 
 
@@ -131,26 +155,28 @@ def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, ba
         shard_x, shard_y = test_images, _np(test_labels)
     else:
         shard_x, shard_y = test_images[s:e], _np(test_labels)[s:e]
-    c, n, roc = model_eval_gan(reconstruct, classifier, shard_x, shard_y, batch_size, rec_rr, first_image=s, **kw)
+    c, n, roc = model_eval_gan(reconstruct, classifier, shard_x, shard_y, batch_size, rec_rr, first_image=s, as_tensors=True, **kw)
     cap = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
-    # one message per rank: [count, labels.., preds.., diffs..] as float64 (exact for these integers)
-    buf = torch.zeros(1 + 3 * cap, dtype=torch.float64, device=device)
+    # ONE message per rank, built where the results already are (the device, with an nccl group): int32
+    # [count | labels (cap) | preds (cap) | diffs (cap, float32 bits)] -- exact, 12 bytes per image (15 KB per rank for the
+    # 1250-image shards of BASELINE configs[4]), one all_gather, one copy back to the host
+    buf = torch.zeros(1 + 3 * cap, dtype=torch.int32, device=device)
     buf[0] = n
-    buf[1:1 + n] = torch.from_numpy(roc[0].astype(np.float64))
-    buf[1 + cap:1 + cap + n] = torch.from_numpy(roc[1].astype(np.float64))
+    buf[1:1 + n] = roc[0].to(device=device, dtype=torch.int32)
+    buf[1 + cap:1 + cap + n] = roc[1].to(device=device, dtype=torch.int32)
     if len(roc[2]):
-        buf[1 + 2 * cap:1 + 2 * cap + n] = torch.from_numpy(roc[2].astype(np.float64))
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
+        buf[1 + 2 * cap:1 + 2 * cap + n] = roc[2].to(device=device, dtype=torch.float32).view(torch.int32)
+    out = torch.empty(world * (1 + 3 * cap), dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    t = out.view(world, 1 + 3 * cap).cpu().numpy()
     labels, preds, diffs = [], [], []
-    for t in out:
-        t = t.cpu().numpy()
-        k = int(t[0])
-        labels.append(t[1:1 + k].astype(np.int64))
-        preds.append(t[1 + cap:1 + cap + k].astype(np.int64))
-        diffs.append(t[1 + 2 * cap:1 + 2 * cap + k].astype(np.float32))
+    for row in t:
+        k = int(row[0])
+        labels.append(row[1:1 + k].astype(np.int64))
+        preds.append(row[1 + cap:1 + cap + k].astype(np.int64))
+        diffs.append(np.ascontiguousarray(row[1 + 2 * cap:1 + 2 * cap + k]).view(np.float32).copy())
     labels, preds, diffs = np.concatenate(labels), np.concatenate(preds), np.concatenate(diffs)
     acc = float((labels == preds).sum()) / max(n_total, 1)
     return acc, [labels, preds, diffs]

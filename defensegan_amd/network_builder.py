@@ -205,8 +205,9 @@ class MLP(object):
     def __call__(self, x):
         return self.get_probs(x)
 
-    def eval_batch(self, rec, orig=None, labels=None):
-        """One batch of model_eval_gan on the device (gan_defense.py:113-179): returns (n_correct, preds [B], diffs [B] or None).
+    def eval_batch(self, rec, orig=None, labels=None, sync=True):
+        """One batch of model_eval_gan on the device (gan_defense.py:113-179): returns (n_correct, preds [B], diffs [B] or None);
+        with ``sync=False`` n_correct stays a device tensor [1] (int32) and the call does not wait for the stream.
         ``rec`` = the classifier's input (reconstructions), ``orig`` = the images they are compared with (diff_op,
         blackbox.py:569-572), ``labels`` int class indices."""
         import torch
@@ -225,7 +226,9 @@ class MLP(object):
             _native.check(_native.load().dg_eval_batch(
                 self._handle, r.data_ptr(), o.data_ptr() if o is not None else None, lab.data_ptr() if lab is not None else None, B,
                 preds.data_ptr(), diffs.data_ptr() if diffs is not None else None, cnt.data_ptr(), stream))
-        return int(cnt.item()), preds, diffs
+        if sync:
+            return int(cnt.item()), preds, diffs
+        return cnt, preds, diffs          # device tensors: nothing waits for the stream (gan_defense.model_eval_gan sums at the end)
 
 
 def conv_output_shape(shape, layer: Conv2D):

@@ -48,27 +48,31 @@ def test_roofline_object_from_a_profile():
     assert kernels == [] and r["kernel"] is None and r["achieved"] == 100.0 and r["traffic"] is None
 
 
-def test_traffic_is_quoted_only_for_the_build_it_was_measured_on(tmp_path, monkeypatch):
-    sym = "gemm_batched_kernel<0, 3, 1>"
-    doc = {"build": bench.build_id(), "mnist": {sym: {"bytes_per_launch": 123}}, "celeba": {sym: {"bytes_per_launch": 7}}}
+def test_traffic_is_quoted_only_for_the_build_and_job_lists_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic: bytes of the LAYERS that ran as the dominant symbol (mean over them), from the committed PMC file --
+    only for the same kernel sources (build id), the same row count and the same job lists (tuning id)."""
+    rows = {"B3": {"kernel": "gemm_batched_kernel<0, 3, 1>", "bytes_per_launch": 100},
+            "B2": {"kernel": "gemm_batched_kernel<0, 3, 1>", "bytes_per_launch": 300},
+            "F3": {"kernel": "gemm_batched_kernel<1, 2, 1>", "bytes_per_launch": 1000}}
+    doc = {"builds": {"mnist": bench.build_id(), "celeba": bench.build_id()}, "tuning_ids": {"mnist": "aaaaaaaaaaaa", "celeba": "bbbbbbbbbbbb"},
+           "mnist": {"by_layer": rows}, "celeba": {"by_layer": {"B5": {"bytes_per_launch": 7}}}}
     prof_dir = tmp_path / "profiles"
     prof_dir.mkdir()
     (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    assert bench.traffic_for("mnist", sym, 256, 10) == (123, "profiles/" + bench.TRAFFIC_FILE)
-    assert bench.traffic_for("fmnist", sym, 256, 10)[0] == 123           # same architecture and row count
-    assert bench.traffic_for("celeba", sym, 128, 10)[0] == 7
-    assert bench.traffic_for("mnist", sym, 50, 10) == (None, None)       # another row count: not measured
-    assert bench.traffic_for("mnist", "some_other_kernel", 256, 10)[0] is None
-    assert bench.traffic_for("mnist_bn", sym, 256, 10) == (None, None)   # --use_bn runs quote nothing
-    doc["builds"] = {"mnist": bench.build_id(), "celeba": "0" * 12}     # per-workload ids: CelebA collected on other sources
+    assert bench.traffic_for("mnist", ["B3", "B2"], 256, 10, "aaaaaaaaaaaa") == (200, "profiles/" + bench.TRAFFIC_FILE)
+    assert bench.traffic_for("mnist", ["F3"], 256, 10, "aaaaaaaaaaaa")[0] == 1000
+    assert bench.traffic_for("fmnist", ["B3"], 256, 10, "aaaaaaaaaaaa")[0] == 100      # same architecture and row count
+    assert bench.traffic_for("celeba", ["B5"], 128, 10, "bbbbbbbbbbbb")[0] == 7
+    assert bench.traffic_for("mnist", ["B3"], 256, 10, "cccccccccccc") == (None, None)    # other job lists ran than were profiled
+    assert bench.traffic_for("mnist", ["B3"], 50, 10, "aaaaaaaaaaaa") == (None, None)     # another row count: not measured
+    assert bench.traffic_for("mnist", ["B3", "B9"], 256, 10, "aaaaaaaaaaaa") == (None, None)    # a layer the file does not hold
+    assert bench.traffic_for("mnist", [], 256, 10, "aaaaaaaaaaaa") == (None, None)
+    assert bench.traffic_for("mnist_bn", ["B3"], 256, 10, "aaaaaaaaaaaa") == (None, None)  # --use_bn runs quote nothing
+    doc["builds"]["celeba"] = "0" * 12                                  # CelebA collected on other kernel sources
     (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
-    assert bench.traffic_for("mnist", sym, 256, 10)[0] == 123
-    assert bench.traffic_for("celeba", sym, 128, 10) == (None, None)
-    del doc["builds"]
-    doc["build"] = "0" * 12                                             # collected on other kernel sources
-    (prof_dir / bench.TRAFFIC_FILE).write_text(json.dumps(doc))
-    assert bench.traffic_for("mnist", sym, 256, 10) == (None, None)
+    assert bench.traffic_for("mnist", ["B3"], 256, 10, "aaaaaaaaaaaa")[0] == 100
+    assert bench.traffic_for("celeba", ["B5"], 128, 10, "bbbbbbbbbbbb") == (None, None)
 
 
 def test_build_id_covers_every_kernel_source_and_header():
@@ -111,14 +115,26 @@ def test_committed_traffic_file_is_well_formed():
     with open(path) as fh:
         doc = json.load(fh)
     for wl in ("mnist", "celeba"):
-        assert len(doc.get("builds", {}).get(wl, doc.get("build"))) == 12
-        assert doc[wl], wl
-        for sym, rec in doc[wl].items():
-            assert rec["bytes_per_launch"] > 0 and rec["launches_profiled"] > 0, (wl, sym)
+        assert len(doc["builds"][wl]) == 12 and len(doc["tuning_ids"][wl]) == 12
+        rows = doc[wl]["by_layer"]
+        assert {"F2", "F3", "B3", "B2"} <= set(rows), wl
+        for layer, rec in rows.items():
+            assert rec["bytes_per_launch"] > 0 and rec["launches_profiled"] > 0 and rec["kernel"], (wl, layer)
             # FETCH_SIZE (KB, doubled per the gfx950 note) + WRITE_SIZE (KB), per launch
-            total = (2.0 * rec["fetch_kb_raw"] + rec["write_kb"]) * 1024.0
-            assert abs(total - rec["bytes_per_launch"]) <= 0.02 * total, (wl, sym)
+            assert abs(rec["bytes_per_launch"] - (2.0 * rec["fetch_kb_raw"] + rec["write_kb"]) * 1024) <= 2048, (wl, layer)
 
+
+def test_pmc_rows_are_labelled_by_the_launch_order_of_an_iteration():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "tools", "pmc_traffic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g, lin = "gemm_batched_kernel<0, 3, 1>", "lin_stationary_kernel<4, 2>"
+    it = [lin, g, g, "mnist_tail_pipe_kernel<64>", g, g, "lin_stationary_kernel<8, 0>", "momentum_update_kernel"]
+    last = [lin, g, g, "mnist_tail_mfma_kernel<64>", "select_kernel"]
+    assert m.layer_labels(it + it + last, "mnist") == ["F1", "F2", "F3", "T5fb", "B3", "B2", "B1", "UPD"] * 2 + ["F1", "F2", "F3", "T5", ""]
+    c = [g] * 4 + ["celeba_tail_fwd_split_kernel<64>", "celeba_tail_bwd_persist_kernel<64>"] + [g] * 4 + ["momentum_update_kernel"]
+    assert m.layer_labels(c, "celeba") == ["F1", "F2", "F3", "F5", "T6f", "T6b", "B5", "B3", "B2", "B1", "UPD"]
 
 def test_gpus_n_never_degrades_to_a_one_gpu_run():
     """`--gpus N` either runs N ranks or exits: launcher present -> WORLD_SIZE must equal N; launcher absent and N > 1 ->

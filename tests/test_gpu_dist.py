@@ -94,3 +94,95 @@ def test_bench_runs_its_rccl_path_with_one_rank(extra):
         assert res["scaling"] == "weak" and res["roofline"]["kernel"] and res["roofline"]["frac"] > 0
         # the untimed event pass: the kernels of one step cannot take longer than a timed step plus launch slack
         assert res["roofline"]["sum_kernel_ms_per_step"] <= 1.10 * res["ms_per_step"] + 2.0
+
+
+_WORKER2 = r"""
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from defensegan_amd import gan_defense as gd, network_builder as nb, synth
+from tests.helpers import make_gan
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ.get("DG_TEST_BACKEND", "nccl")
+gpu = 0 if os.environ.get("DG_TEST_SAME_DEVICE") == "1" else rank
+torch.cuda.set_device(gpu)
+if backend == "nccl":
+    dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+else:
+    dist.init_process_group(backend)
+try:
+    R, N = 3, 90
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=6, device=gpu)
+    # rank 0 times the job lists, the others install its choices: identical lists everywhere
+    if rank == 0:
+        gan.prepare(32)
+        text = [gan.export_tuning()]
+    else:
+        text = [None]
+    dist.broadcast_object_list(text, src=0)
+    if rank != 0:
+        gan.import_tuning(text[0])
+        gan.prepare(32)
+    ids = [None] * world
+    dist.all_gather_object(ids, gan.tuning_id())
+    x = np.asarray(gan.generate(synth.make_z(N, 128, seed=4)).cpu())
+    x = synth.adversarial(x, 0.3, 0.0, 1.0, seed=5)
+    clf = nb.model_a(nb_filters=8)
+    clf._device = gpu
+    clf.init_like_reference(seed=6)
+    labels = np.asarray(clf.fprop(x)["logits"].argmax(axis=1))
+    acc, roc = gd.model_eval_gan_sharded(gan.reconstruct, clf, x, labels, batch_size=32, rec_rr=R, seed=77)
+    s0, e0 = gd.shard_range(N, rank, world)
+    rec = gan.reconstruct(x[s0:e0], seed=77, first_row=s0 * R)
+    whole = gd.gather_shards(np.asarray(rec.cpu() if hasattr(rec, "cpu") else rec), N)
+    out = {"rank": rank, "backend": dist.get_backend(), "world": dist.get_world_size(), "acc": acc, "ids": ids,
+           "preds": roc[1].tolist(), "diffs": [float(v) for v in roc[2]], "rec_sum": float(np.abs(whole).sum())}
+    if rank == 0:
+        c, n, roc1 = gd.model_eval_gan(gan.reconstruct, clf, x, labels, batch_size=N, rec_rr=R, seed=77)
+        rec1 = np.asarray(gan.reconstruct(x, seed=77, first_row=0))
+        out.update({"acc1": c / n, "preds_equal": bool((roc[1] == roc1[1]).all()), "diffs_equal": bool(np.array_equal(roc[2], roc1[2])),
+                    "gather_equal": bool(np.array_equal(whole, rec1))})
+    print("RESULT " + json.dumps(out))
+finally:
+    dist.destroy_process_group()
+"""
+
+
+def _run_two_ranks(**extra):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = _env(RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_PORT=str(port), **extra)
+        procs.append(subprocess.Popen([sys.executable, "-c", _WORKER2 % {"root": ROOT}], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    res = []
+    for p in procs:
+        out, err = p.communicate(timeout=900)
+        assert p.returncode == 0, out[-2000:] + err[-4000:]
+        res.append(json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):]))
+    res.sort(key=lambda r: r["rank"])
+    assert [r["world"] for r in res] == [2, 2]
+    assert res[0]["ids"] == res[1]["ids"] and len(set(res[0]["ids"])) == 1            # the same job lists on both ranks
+    assert res[0]["preds"] == res[1]["preds"] and res[0]["diffs"] == res[1]["diffs"] and res[0]["rec_sum"] == res[1]["rec_sum"]
+    assert res[0]["preds_equal"] and res[0]["diffs_equal"] and res[0]["gather_equal"]
+    assert abs(res[0]["acc"] - res[0]["acc1"]) < 1e-12
+    return res
+
+
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """World size 2 on real GPUs (skipped on the 1-GPU test boxes): one process per GPU, nccl = RCCL; rank 0's timed job lists
+    are installed on rank 1 (same tuning id); every rank evaluates its contiguous image shard with its own engine, ONE
+    all_gather assembles (labels, preds, diffs) -- identical on both ranks and bit-identical to one GPU doing everything."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (device_count = %d)" % torch.cuda.device_count())
+    res = _run_two_ranks()
+    assert [r["backend"] for r in res] == ["nccl", "nccl"]
+
+
+def test_two_rank_worker_on_one_gpu_over_gloo():
+    """The same two-rank worker with both ranks on GPU 0 and a gloo group (RCCL refuses two ranks on one device): everything
+    but the transport -- the tuning hand-over between processes, two engines evaluating their shards, the device-built int32
+    message and its single all_gather -- runs on the 1-GPU test box."""
+    res = _run_two_ranks(DG_TEST_BACKEND="gloo", DG_TEST_SAME_DEVICE="1")
+    assert [r["backend"] for r in res] == ["gloo", "gloo"]

@@ -86,8 +86,7 @@ def make_latents(zseed, B, R):
     z0 = (rs.standard_normal((B * R, LATENT)) * std).astype(np.float32)
     if R >= 3:
         z0[2] = z0[1]            # a duplicated restart: the first-minimum tie-break of tf.argmin
-    noise = np.sign(np.random.RandomState(zseed + 1).standard_normal([B] + image_dim("celeba" if False else "mnist"))).astype(np.float32)
-    return zt, z0, noise
+    return zt, z0
 
 
 def sign_noise(zseed, shape):
@@ -105,7 +104,7 @@ def self_check():
     out = {}
     for name, arch, wseed, gain, bias_range, B, R, adv, zseed in CASES:
         w, names = make_weights(arch, wseed, gain, bias_range)
-        zt, z0, _ = make_latents(zseed, B, R)
+        zt, z0 = make_latents(zseed, B, R)
         out[name] = {"weights": digest([w[k] for k in names]), "z_true": digest([zt]), "z0": digest([z0]),
                      "noise": digest([sign_noise(zseed, [B] + image_dim(arch))])}
     return out
@@ -119,7 +118,7 @@ def run_reference(ref_root, out_dir, iters):
 
     for name, arch, wseed, gain, bias_range, B, R, adv, zseed in CASES:
         w, names = make_weights(arch, wseed, gain, bias_range)
-        zt, z0, _ = make_latents(zseed, B, R)
+        zt, z0 = make_latents(zseed, B, R)
         dim = image_dim(arch)
         lo = -1.0 if arch == "celeba" else 0.0
         result = {"arch": arch, "wseed": wseed, "gain": gain, "bias_range": bias_range, "R": R, "lr": 10.0, "momentum": 0.7,
@@ -136,10 +135,16 @@ def run_reference(ref_root, out_dir, iters):
                     def _load_dataset(self):
                         pass
 
-                cfg = {"DATASET_NAME": arch, "BATCH_SIZE": batch, "USE_BN": False, "LATENT_DIM": LATENT, "NET_DIM": NET_DIM,
-                       "REC_ITERS": L, "REC_RR": rr, "REC_LR": 10.0, "IMAGE_DIM": dim}
-                model = NoData(cfg=cfg, test_mode=True, verbose=False, dataset_name=arch, batch_size=batch, use_bn=False,
-                               latent_dim=LATENT, net_dim=NET_DIM, rec_iters=L, rec_rr=rr, rec_lr=10.0, image_dim=dim)
+                # AbstractModel.__init__ (models/base_model.py:29-84) reads cfg['cfg_path'] for its checkpoint directory and
+                # resolves every attribute it is not given from tf.app.flags / cfg (None otherwise): give it all of them
+                cfg = {"cfg_path": "experiments/cfgs/gans/%s.yml" % {"f-mnist": "fmnist"}.get(arch, arch), "DATASET_NAME": arch,
+                       "BATCH_SIZE": batch, "USE_BN": False, "LATENT_DIM": LATENT, "NET_DIM": NET_DIM, "REC_ITERS": L, "REC_RR": rr,
+                       "REC_LR": 10.0, "IMAGE_DIM": dim}
+                model = NoData(cfg=cfg, test_mode=True, verbose=False, dataset_name=arch, batch_size=batch, test_batch_size=batch,
+                               use_bn=False, latent_dim=LATENT, net_dim=NET_DIM, rec_iters=L, rec_rr=rr, rec_lr=10.0, image_dim=dim,
+                               mode="gp-wgan", gradient_penalty_lambda=10.0, train_iters=1, critic_iters=5, input_transform_type=0,
+                               debug=False, test_again=False, loss_type="l2", attribute="gender", tensorboard_log=False,
+                               output_dir=os.path.join(out_dir, "tf_scratch"), num_gpus=1)
                 x_pl = tf.placeholder(tf.float32, shape=[batch] + dim)
                 z_pl = tf.placeholder(tf.float32, shape=[batch * rr, LATENT])
                 rec_op = model.reconstruct(x_pl, batch_size=batch, z_init_val=z_pl)
