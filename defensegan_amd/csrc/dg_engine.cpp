@@ -797,9 +797,16 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
         each_op([&](GemmOp& op, int, int, int) { if (!lin_stationary(h, op) && !find_jobs(op, rows[i])) missing = true; return 0; });
     if (!missing) return DG_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+    // (an error from the query -- the legacy NULL stream while another stream captures in global mode -- is treated as "capturing":
+    // what follows synchronises the device and allocates)
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
         return fail(DG_E_STATE, "this call shape has not been prepared and the stream is being captured: call dg_prepare(B, R) "
                                 "before the capture (it allocates workspace and times the job lists)");
+    }
+    // One handle serves ONE stream at a time (include/defensegan_hip.h): the timing launches below write the handle's own
+    // activation buffers, so whatever an earlier call left queued on another stream must have finished first
+    HIP_TRY(hipDeviceSynchronize());
     int rc = ensure_workspace(h, cap_rows);
     if (rc) return rc;
     for (int i = 0; i < n; ++i) {
@@ -1404,6 +1411,9 @@ int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream)
     int n_checked = 0;
     rc = check_rows(N, 1, &n_checked);
     if (rc) return rc;
+    // every row is compared with image 0 by passing R = N: the tails' row -> image division (a 40-bit magic multiply) is exact
+    // for row * R < 2^40 only
+    if (N > (1 << 20)) return fail(DG_E_INVALID, "dg_generate: at most %d rows per call (got %d): split the batch", 1 << 20, N);
     HIP_TRY(hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
     rc = prepare_rows(h, N, &N, 1, s);

@@ -1087,6 +1087,7 @@ __device__ __forceinline__ void celeba_tail_fwd_split_body(const CelebaTailArgs&
     auto item_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
     for (int i = tid; i < 5 * KK * 64; i += 512)
         reinterpret_cast<f32x4v*>(sW)[i] = reinterpret_cast<const f32x4v*>(a.F6p)[i];
+    if (tid < CES_UNITS) sP[tid * CE16_UNIT + 16] = 0.f;          // the word taps that do not exist read (see the G role)
     // (Measured and removed: delaying one of a CU's two workgroups by 2-8 k cycles to de-phase them, 152.0-153.4 vs 152.1 us;
     // s_setprio 2 for the M waves, 149.6 vs 150.3 us.)
     if (wave < 4) {
@@ -1239,8 +1240,10 @@ __device__ __forceinline__ void celeba_tail_fwd_split_body(const CelebaTailArgs&
         const int g = wave - 4;                                          // output row il of the half-band
         const int j = lane;                                              // output column; channels co = 0..2
         const float gscale = 2.0f / 12288.0f;
-        // column terms: offsets ow * 17 + kw * 3 + co of the <= 3 taps kw = kw0 + 2 aw; a tap that does not exist reads the unit's
-        // zero pad column (kappa' = 15 of position 0: the filter pack's 16th column is zero)
+        // column terms: offsets ow * 17 + kw * 3 + co of the <= 3 taps kw = kw0 + 2 aw; a tap that does not exist reads word 16 of
+        // the unit -- the pitch pad of position 0, which no MFMA result is ever stored to and which is zeroed explicitly when the
+        // workgroup starts (a COMPUTED zero, position 0 times the pack's zero 16th column, would turn an Inf / NaN in that
+        // input position into NaNs along the whole image border)
         int colofs[3][3];
         float bias[3];
         {
@@ -1252,7 +1255,7 @@ __device__ __forceinline__ void celeba_tail_fwd_split_body(const CelebaTailArgs&
                 for (int aw = 0; aw < 3; ++aw) {
                     const int kw = kw0 + 2 * aw;
                     const int ow = (j + 1 - kw) >> 1;
-                    colofs[co][aw] = (kw > 4 || ow < 0 || ow >= 32) ? 15 : ow * CE16_PITCH + kw * 3 + co;
+                    colofs[co][aw] = (kw > 4 || ow < 0 || ow >= 32) ? 16 : ow * CE16_PITCH + kw * 3 + co;
                 }
             }
         }

@@ -418,8 +418,10 @@ class DefenseGANBase(object):
         H, W, Cc = self._arch.image_dim
         y = torch.empty(N, H, W, Cc, dtype=torch.float32, device=zz.device)
         with torch.cuda.device(zz.device):
-            self._check(lib.dg_generate(self._handle, zz.data_ptr(), N, y.data_ptr(),
-                                          torch.cuda.current_stream(zz.device).cuda_stream))
+            for r0 in range(0, N, 1 << 20):                   # dg_generate takes at most 2^20 rows per call
+                n = min(1 << 20, N - r0)
+                self._check(lib.dg_generate(self._handle, zz[r0:r0 + n].data_ptr(), n, y[r0:r0 + n].data_ptr(),
+                                              torch.cuda.current_stream(zz.device).cuda_stream))
         return y.cpu().numpy() if was_numpy else y
 
     def loss_grad(self, images, z):

@@ -106,10 +106,13 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
  * this (B, R) and dg_generate with N = B*R are asynchronous in the strict sense documented at dg_reconstruct.  Shapes stay
  * prepared until an option that changes the lists is set (at most 16 row counts are kept per layer, oldest dropped first).
  * Results never depend on which list was chosen (tiles are only cut along M / N): preparing is about latency only.
+ * A handle serves ONE stream at a time: dg_prepare (and the self-preparation of a call with a new shape) waits for the
+ * device and then times launches on the handle's own activation buffers -- work of the same handle still queued on another
+ * stream is waited for, not overlapped.
  */
 int dg_prepare(dg_handle* h, int B, int R, void* stream);
 
-/* G(z): z [N, latent] -> y [N, H, W, C].  (generator_fn(z, is_training=False), gan.py:399) */
+/* G(z): z [N, latent] -> y [N, H, W, C], N <= 2^20 rows per call.  (generator_fn(z, is_training=False), gan.py:399) */
 int dg_generate(dg_handle* h, const float* z, int N, float* out_y, void* stream);
 
 /*

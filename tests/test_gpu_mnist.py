@@ -181,10 +181,13 @@ def test_full_size_contractive_regime_properties():
     # rec is G(z_{L-1}) of the selected row
     y_sel = gan.generate(out["z"][rows])
     np.testing.assert_allclose(out["rec"], y_sel, rtol=0, atol=1e-6)
-    # oracle on the first 16 images (rows are independent, so a subset is a valid check)
+    # FLOAT64 oracle (the torch restatement run in double precision) on the first 32 images (rows are independent, so a
+    # subset is a valid check)
+    import torch
     from oracle import torch_ref as T
-    nb = 16
-    t = T.reconstruct(p, x[:nb], z0[:nb * R], R, L, lr=10.0, momentum=0.7, arch="mnist")
+    nb = 32
+    t = T.reconstruct(p, x[:nb].astype(np.float64), z0[:nb * R].astype(np.float64), R, L, lr=10.0, momentum=0.7, arch="mnist",
+                      dtype=torch.float64)
     mse = ((out["rec"][:nb] - t["rec"]) ** 2).reshape(nb, -1).mean(axis=1)
     assert (mse < 1e-4).all(), mse
     gap = np.sort(t["loss"].reshape(nb, R), axis=1)

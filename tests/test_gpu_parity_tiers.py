@@ -124,8 +124,11 @@ def test_distributional_tier_on_the_bench_inputs(workload, nb):
         # part of the run (from ~L = 20 on) one of them occasionally exceeds half the gap on an image where torch-float32's did
         # not (measured on MI355X, MNIST: L = 5 / 10 / 20 all decidable images agree, L = 50 one of ~30 differs, L = 200 19 of 19
         # agree).  While rounding is not yet amplified every decidable image must agree; later at least 9 in 10.
-        need = 1.0 if Lh <= 10 else 0.9
-        assert dec.sum() == 0 or agree.mean() >= need, (Lh, int(dec.sum()), int(agree.sum()), sel, h64.argmin(axis=1), dec)
+        # A tolerated mismatch needs company: with fewer than 10 decidable images none is allowed (one of very few cannot pass
+        # as "9 in 10").
+        n_dec, n_bad = int(dec.sum()), int((~agree).sum())
+        allowed = 0 if (Lh <= 10 or n_dec < 10) else n_dec // 10
+        assert n_bad <= allowed, (Lh, n_dec, n_bad, sel, h64.argmin(axis=1), dec)
         agreement[Lh] = (int(agree.sum()), int(dec.sum()))
         # the per-restart losses themselves: 9 rows in 10 within 3 x the float32 restatement's own largest distance from
         # float64 at this horizon (plus float32 resolution) -- tight while rounding is not yet amplified, loose in the chaos
@@ -136,3 +139,45 @@ def test_distributional_tier_on_the_bench_inputs(workload, nb):
     assert max(fracs.values()) >= 0.25, fracs                           # the selection comparison is not vacuous
     if workload == "mnist":
         assert fracs[L] >= 0.25, fracs
+
+
+def test_celeba_clean_targets_at_the_reference_lr_up_to_the_longest_decidable_horizon():
+    """BASELINE configs[3] at the reference's lr = 10 on CLEAN in-range targets x = G(z_true) (the adversarial inputs of the
+    bench are chaotic from ~L = 20 on, so their selection can only be compared at short horizons): the first 16 images of the
+    128-image batch, R = 10, one torch-float32 and one torch-float64 run to L = 200 yielding every horizon's per-restart losses.
+    At the LONGEST horizon where at least half of the images are decidable (float64 top-2 gap above twice the float32 spread)
+    the device must select float64's restart on every decidable image and its per-restart losses must sit inside the float32
+    restatement's own distance from float64; the horizon found is printed (and must be at least 10)."""
+    from oracle import torch_ref as T
+    from tests.helpers import decidable
+    arch, B, R, L, nb = "celeba", 128, 10, 200, 16
+    horizons = (5, 10, 20, 50, 100, 200)
+    gan, p = make_gan(arch, wseed=1234, gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=L, rec_lr=10.0)
+    x = gan.generate(gan.init_latents(B, seed=1000, first_row=0)).contiguous()           # clean targets, keyed by the image index
+    z0 = gan.init_latents(B * R, seed=2024, first_row=0)
+    xs, zs = x[:nb].cpu().numpy(), z0[:nb * R].cpu().numpy()
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch=arch, loss_at=horizons)
+    t64 = T.reconstruct(p, xs.astype(np.float64), zs.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch=arch,
+                        dtype=torch.float64, loss_at=horizons)
+    frac = {}
+    for Lh in horizons:
+        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        frac[Lh] = float(decidable(h32, h64).mean())
+    usable = [Lh for Lh in horizons if frac[Lh] >= 0.5]
+    print("decidable fraction by horizon (clean CelebA targets, lr = 10): %s" % frac)
+    assert usable and max(usable) >= 10, frac
+    for Lh in sorted(set([usable[0], max(usable)])):
+        gan.rec_iters = Lh
+        o = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
+        ld = o["loss"].cpu().numpy().reshape(nb, R).astype(np.float64)
+        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        dec = decidable(h32, h64)
+        sel = o["idx"].cpu().numpy()
+        assert (sel[dec] == h64.argmin(axis=1)[dec]).all(), (Lh, sel, h64.argmin(axis=1), dec)
+        tol = 3.0 * np.abs(h32 - h64).max() + 4e-6 * np.abs(h64)
+        assert (np.abs(ld - h64) <= tol).mean() >= 0.9, (Lh, np.abs(ld - h64).max(), np.abs(h32 - h64).max())
+        # the selected reconstruction's error is the loss the call reports
+        mse = ((o["rec"] - x[:nb]) ** 2).flatten(1).mean(dim=1).cpu().numpy()
+        np.testing.assert_allclose(mse, ld.min(axis=1), rtol=2e-4, atol=1e-9)
+    print("longest decidable horizon: L = %d (%.0f %% of %d images)" % (max(usable), 100 * frac[max(usable)], nb))
