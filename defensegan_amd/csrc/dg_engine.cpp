@@ -166,6 +166,7 @@ struct dg_handle {
     int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
                                    // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
+    int tail_pipe_version = 2;     // 2 = mnist_tail_pipe2_kernel, 1 = mnist_tail_pipe_kernel (dg_tail_mfma.hip)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
     // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
@@ -199,7 +200,11 @@ struct dg_handle {
     struct LoopGraph { int B = 0, R = 0, L = 0; float lr = 0.f, momentum = 0.f; int lr_intended = 0; uint64_t epoch = 0; hipGraphExec_t exec = nullptr; };
     std::vector<LoopGraph> graphs;
     uint64_t list_epoch = 0;
-    int graph_max_rows = 1024;
+    // OFF by default (0).  Measured in round 4 on the reference's default batch (500 rows): 780.4 img/s replayed vs 779.5 enqueued
+    // (profiles/r04_exp_loop_graph.txt) -- the loop is not launch-bound (a kernel lasts 40 us on average) -- and on ROCm 7.2 a graph
+    // the CALLER captured of a call on this handle (tests/test_gpu_prepare.py) replays with wrong results once an internal replay
+    // has run between its capture and its replay (4 runs in 5; eager launches in between are harmless; tools/graph_interplay_repro.py).
+    int graph_max_rows = 0;
     bool graph_broken = false;     // a capture / instantiate failed once: stay on the eager path
     float* xbuf = nullptr;
     int64_t xbuf_floats = 0;
@@ -885,13 +890,14 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
         t.pipe = h->tail_pipe;
+        t.pipe_version = h->tail_pipe_version;
 #ifdef DG_MEASURE
         t.dbg = h->tail_dbg;
         t.trace = h->d_tail_trace;
 #endif
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         const bool piped = t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
-        ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? "T5fb@mnist_tail_pipe_kernel" : "T5fb@mnist_tail_mfma_kernel",
+        ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? (t.pipe_version == 2 ? "T5fb@mnist_tail_pipe2_kernel" : "T5fb@mnist_tail_pipe_kernel") : "T5fb@mnist_tail_mfma_kernel",
                      (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         dg::launch_mnist_tail_mfma(t, s);
     }
@@ -1364,8 +1370,15 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
             hipGraphExec_t exec = loop_graph(h, B, R, L, lr, momentum);
             if (exec) {
+                // The graph runs on the engine's own stream, tied to the caller's by events on both sides (measured: a graph
+                // launched straight into the legacy NULL stream -- torch's default stream -- was not ordered against the
+                // launches that followed it there)
                 HIP_TRY(hipMemcpyAsync(h->xbuf, x, (size_t)B * h->P * sizeof(float), hipMemcpyDeviceToDevice, s));
-                HIP_TRY(hipGraphLaunch(exec, s));
+                HIP_TRY(hipEventRecord(h->ev_fork, s));
+                HIP_TRY(hipStreamWaitEvent(h->cap_stream, h->ev_fork, 0));
+                HIP_TRY(hipGraphLaunch(exec, h->cap_stream));
+                HIP_TRY(hipEventRecord(h->ev_join[0], h->cap_stream));
+                HIP_TRY(hipStreamWaitEvent(s, h->ev_join[0], 0));
                 replayed = true;
             }
         } else {
@@ -1627,6 +1640,11 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "tail_pipe") {
         h->tail_pipe = atoi(value);
+        return DG_OK;
+    }
+    if (k == "tail_pipe_version") {
+        if (atoi(value) != 1 && atoi(value) != 2) return fail(DG_E_INVALID, "tail_pipe_version: 1 or 2");
+        h->tail_pipe_version = atoi(value);
         return DG_OK;
     }
     if (k == "tail_fwd_split") {

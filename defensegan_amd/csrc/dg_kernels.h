@@ -121,6 +121,7 @@ struct MnistTailArgs {
     int C;               // net_dim (64)
     int do_backward;
     int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
+    int pipe_version;    // 2: mnist_tail_pipe2_kernel (matrix work levelled over the SIMDs, positions 192..195 on the gather waves); 1: mnist_tail_pipe_kernel
 #ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
     long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr

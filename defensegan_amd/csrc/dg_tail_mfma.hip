@@ -625,13 +625,306 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe_kernel(MnistTailArgs a) {
     }
 }
 
+
+// ---- pipelined variant, second generation: the matrix work levelled over the four SIMDs ---------------------------------
+// In mnist_tail_pipe_kernel wave w < 7 owns position tile w for both GEMMs: waves (0,4), (1,5), (2,6) share a SIMD, so three
+// SIMDs carry two tiles = 116 MFMAs per step (7.4 k cycles of matrix pipe) and the fourth one tile -- and tile 6 is 4 real
+// positions (192..195) padded to 32.  The M waves are the step's critical path (~11 k of 13 k cycles, tools/tail_trace_mnist.py),
+// mostly waiting for each other's MFMAs.  Here
+//   waves 0-3   forward + backward of tile w                     (58 MFMAs)
+//   waves 4, 5  forward of tile w only                           (32)
+//   waves 6, 7  backward of tiles 4, 5 (masks, da5 image and filter fragments are in LDS: any wave can do it; the masked
+//               tile goes through a 4 KB scratch in the wave's own, otherwise unused staging region)          (26)
+//   the 4 positions of "tile 6" leave the matrix pipe: the gather waves compute their 4 x 25 P entries, their ReluGrad bits and
+//   their 4 x 64 gradients with v_fma chains in the MFMA's k order (bit-identical: an MFMA is a k-ordered fma chain), from a
+//   1 KB image one of them stages by LDS-DMA two rows ahead
+// so every SIMD carries 84-90 MFMAs per step (5.8 k cycles) and no MFMA is spent on padding rows.  Same barrier sequence, same
+// buffers and the same arithmetic per element as mnist_tail_pipe_kernel (tests/test_gpu_variants.py: bit-identical).
+template <int C>
+__global__ __launch_bounds__(768) void mnist_tail_pipe2_kernel(MnistTailArgs a) {
+    static_assert(C == 64, "64 channels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PSZ = 224 * MN_NKP, GSZ = MN_GR * MN_GWP, MSZ = 224 * (C / 32);
+    float* sP = reinterpret_cast<float*>(smem);                  // [2][224][MN_NKP]
+    float* sg = sP + 2 * PSZ;                                    // [2][31][32]
+    unsigned* smask = reinterpret_cast<unsigned*>(sg + 2 * GSZ); // [2][224][C/32]: tiles 0-5
+    float* sred = reinterpret_cast<float*>(smask + 2 * MSZ);     // [2][4]
+    float* sWf = sred + 8;                                       // forward filter fragments [C/8][64][4]
+    float* sWb = sWf + (C / 8) * 256;                            // backward filter fragments [13][64][C/32]
+    char* stages = reinterpret_cast<char*>(sWb + 13 * 64 * (C / 32));     // [8 waves][8 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool mrole = wave < 8;
+    const bool has_fwd = wave < 6;                               // forward GEMM of tile `wave`
+    const bool has_bwd = wave < 4 || wave == 6 || wave == 7;     // backward GEMM of tile btile
+    const int tile = wave;                                       // forward tile
+    const int btile = wave < 4 ? wave : wave - 2;                // backward tile (waves 6, 7 -> tiles 4, 5)
+    char* stage = stages + (wave & 7) * (32 * C * 4);            // waves 0-5: A tile [32][C], LDS-DMA target
+    // wave 6's region: [2][4 positions][C] images of positions 192..195 (rows t+1 / t+2), then wave 6's scratch; wave 7's: scratch
+    float* la = reinterpret_cast<float*>(stages + 6 * (32 * C * 4));
+    float* scratch = reinterpret_cast<float*>(stages + (wave & 7) * (32 * C * 4) + 2048);
+    unsigned* lmask = reinterpret_cast<unsigned*>(stages + 7 * (32 * C * 4) + 2048 + 4096);   // [3][C] ReluGrad bits of 192..195, by row % 3
+    // ReluGrad bits of tiles 4, 5, by row % 3: their backward (waves 6, 7, row t-1) runs while their forward (waves 4, 5,
+    // row t+1 -- the same parity) writes the next bits; tiles 0-3 are read and rewritten by one wave in sequence (parity is enough)
+    unsigned* xmask = reinterpret_cast<unsigned*>(stages + 6 * (32 * C * 4) + 2048 + 4096);   // [3][2][C]
+    const int gt = tid - 512;                                    // gather thread id (G waves)
+    const int gw = wave - 8;
+    const int n_my = ((int)a.n_rows - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto row_of = [&](int k) { return (long long)blockIdx.x + (long long)k * gridDim.x; };
+
+    for (int i = tid; i < 2 * GSZ; i += 768) sg[i] = 0.f;       // zero borders of both da5 images, written once
+    for (int i = tid; i < (C / 8) * 256; i += 768) {
+        const int e = i & 3, l = (i >> 2) & 63, kk = i >> 8;
+        const int kappa = l & 31, c = kk * 8 + (l >> 5) * 4 + e;
+        sWf[i] = kappa < 25 ? a.F5[kappa * C + c] : 0.f;
+    }
+    for (int i = tid; i < 13 * 64 * (C / 32); i += 768) {
+        const int u = i % (C / 32), l = (i / (C / 32)) & 63, st = i / (64 * (C / 32));
+        const int kappa = 2 * st + (l >> 5);
+        sWb[i] = kappa < 25 ? a.F5[kappa * C + u * 32 + (l & 31)] : 0.f;
+    }
+    const int q = tile * 32 + frow;                              // this lane's position in the forward role (tiles 0-5: always valid)
+    constexpr int CH = C / 4;                                    // 16-B chunks per position
+    constexpr int NI = 32 * CH / 64;                             // DMA instructions per tile
+    auto stage_row = [&](int k) {
+        const char* src = reinterpret_cast<const char*>(a.h3 + row_of(k) * (196 * C) + (long long)tile * 32 * C);
+#pragma unroll
+        for (int qi = 0; qi < NI; ++qi) {
+            const int slot = qi * 64 + lane;
+            const int pos = slot / CH, c = slot % CH;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                (__attribute__((address_space(3))) void*)(stage + qi * 1024), 16, 0, 0);
+        }
+    };
+    auto read_frags = [&](f32x4 (&av)[C / 8]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < C / 8; ++kk)
+            av[kk] = *reinterpret_cast<const f32x4*>(stage + frow * (C * 4) + (((kk * 2 + fh) ^ (frow & (CH - 1))) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto fwd = [&](int k, const f32x4 (&av)[C / 8]) {
+        unsigned* mk = tile < 4 ? smask + (k & 1) * MSZ + tile * C : xmask + ((k % 3) * 2 + (tile - 4)) * C;
+        int word = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long bal = __ballot(av[kk][e] > 0.f);
+                lo[e] = __builtin_amdgcn_readfirstlane((unsigned)bal);
+                hi[e] = __builtin_amdgcn_readfirstlane((unsigned)(bal >> 32));
+            }
+            // (a v_cmp result SGPR is not safe as the data operand of a v_writelane issued right behind it on gfx950: 4 wait states)
+            asm volatile("s_nop 3\n\t"
+                         "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"
+                         "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                         "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"
+                         "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                         : "+v"(word)
+                         : "s"(lo[0]), "s"(lo[1]), "s"(lo[2]), "s"(lo[3]), "s"(hi[0]), "s"(hi[1]), "s"(hi[2]), "s"(hi[3]),
+                           "i"(8 * kk), "i"(8 * kk + 1), "i"(8 * kk + 2), "i"(8 * kk + 3),
+                           "i"(8 * kk + 4), "i"(8 * kk + 5), "i"(8 * kk + 6), "i"(8 * kk + 7));
+        }
+        mk[lane] = (unsigned)word;
+        tail_fwd_compute_ldsw<C>(av, tile * 32, sWf, sP + (k & 1) * PSZ, MN_NKP, lane);
+    };
+    auto bwd = [&](int k) {
+        const unsigned* mk = btile < 4 ? smask + (k & 1) * MSZ + btile * C : xmask + ((k % 3) * 2 + (btile - 4)) * C;
+        float* hrow = a.h3 + row_of(k) * (196 * C);
+        const int qq = btile * 32 + frow;                        // tiles 0-5: every position exists
+        const int oh = qq / 14, ow = qq - oh * 14;
+        f32x16 acc[C / 32];
+        tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, (2 * oh) * MN_GWP + 2 * ow, true, sWb, acc, lane);
+        // transposition scratch: waves 0-3 their own tile of the P buffer of the same parity (free until their forward GEMM
+        // later in this step rewrites it), waves 6 / 7 a private 4 KB (the P tiles 4 / 5 belong to waves 4 / 5, who are
+        // writing them right now)
+        float* tb = wave < 4 ? sP + (k & 1) * PSZ + btile * 32 * MN_NKP : scratch;
+        const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < C / 32; ++u) {
+            const unsigned mw = mk[u * 32 + frow];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pr = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                tb[pr * 32 + frow] = ((mw >> pr) & 1u) ? acc[u][e] : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int qr = btile * 32 + p * 8 + er;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+                *reinterpret_cast<f32x4*>(hrow + qr * C + u * 32 + ec) = v;
+            }
+        }
+    };
+    const float bias = a.b5[0];
+    const float gscale = 2.0f / 784.0f;
+    auto load_x = [&](int k, float (&xv)[4]) {
+        const float* xrow = a.x + (long long)((unsigned)row_of(k) / (unsigned)a.R) * 784;     // rows < 2^24: 32-bit division
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            xv[r] = p < 784 ? xrow[p] : 0.f;
+        }
+    };
+    auto gather = [&](int k, const float (&xv)[4]) {
+        const float* pP = sP + (k & 1) * PSZ;
+        float* pg = sg + (k & 1) * GSZ;
+        const long long n = row_of(k);
+        float sq = 0.f;
+        float tv[4][9];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            const int i = p / 28, j = p - i * 28;
+            const int kh0 = (i + 1) & 1, kw0 = (j + 1) & 1;
+#pragma unroll
+            for (int ah = 0; ah < 3; ++ah) {
+                const int kh = kh0 + 2 * ah;
+                const int oh = (i + 1 - kh) >> 1;
+                const bool okh = p < 784 && !(kh > 4 || oh < 0 || oh >= 14);
+#pragma unroll
+                for (int aw = 0; aw < 3; ++aw) {
+                    const int kw = kw0 + 2 * aw;
+                    const int ow = (j + 1 - kw) >> 1;
+                    const bool ok = okh && !(kw > 4 || ow < 0 || ow >= 14);
+                    tv[r][ah * 3 + aw] = pP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" : "+v"(tv[r][t]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = gt + 256 * r;
+            if (p >= 784) break;
+            const int i = p / 28, j = p - i * 28;
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) sacc += tv[r][t];
+            const float y = 1.0f / (1.0f + expf(-(sacc + bias)));
+            const float d = y - xv[r];
+            sq = __builtin_fmaf(d, d, sq);
+            pg[(i + 1) * MN_GWP + (j + 1)] = gscale * d * y * (1.0f - y);
+            if (a.y) a.y[n * 784 + p] = y;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) sq += __shfl_xor(sq, m, 64);
+        if (lane == 0) sred[(k & 1) * 4 + gw] = sq;
+    };
+    auto finish_loss = [&](int k) {       // after the barrier that follows gather(k)
+        const float* r4 = sred + (k & 1) * 4;
+        a.loss[row_of(k)] = ((r4[0] + r4[1]) + (r4[2] + r4[3])) * (1.0f / 784.0f);
+    };
+    // ---- positions 192..195 on the gather waves (plain fma chains in the MFMA's k order) ---------------------------------
+    auto stage_left = [&](int k) {        // one wave: 4 positions x C floats = 1 KB, contiguous in h3
+        if (gw != 0) return;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a.h3 + row_of(k) * (196 * C) + 192 * C + lane * 4),
+            (__attribute__((address_space(3))) void*)(la + (k & 1) * (4 * C)), 16, 0, 0);
+    };
+    auto left_fwd = [&](int k) {
+        const float* A = la + (k & 1) * (4 * C);
+        if (gt < C) {                     // ReluGrad bits of the 4 positions, one word per channel (bit p = position 192 + p)
+            unsigned w = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w |= (A[p * C + gt] > 0.f ? 1u : 0u) << p;
+            lmask[(k % 3) * C + gt] = w;
+        }
+        if (gt < 100) {                   // P[192 + qp][kappa] = sum_c h[c] F[kappa][c], c in the order of the MFMA k-steps
+            const int qp = gt / 25, kappa = gt - qp * 25;
+            float acc = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < C / 8; ++kk) {
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(A + qp * C + kk * 8);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(A + qp * C + kk * 8 + 4);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + kappa) * 4);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + 32 + kappa) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(h0[e], w0[e], acc);
+                    acc = __builtin_fmaf(h1[e], w1[e], acc);
+                }
+            }
+            sP[(k & 1) * PSZ + (192 + qp) * MN_NKP + kappa] = acc;
+        }
+    };
+    auto left_bwd = [&](int k) {          // dH[192 + qp][c] = sum_kappa G[kappa] F[kappa][c], kappa ascending (the MFMA k order)
+        const int qp = gt >> 6, c = gt & 63;
+        const float* pg = sg + (k & 1) * GSZ + (2 * 13) * MN_GWP + 2 * (10 + qp);      // position 192 + qp = (oh 13, ow 10 + qp)
+        float acc = 0.f;
+#pragma unroll
+        for (int kappa = 0; kappa < 25; ++kappa) {
+            const float gv = pg[(kappa / 5) * MN_GWP + (kappa % 5)];
+            const float wv = sWb[((kappa >> 1) * 64 + (kappa & 1) * 32 + (c & 31)) * (C / 32) + (c >> 5)];
+            acc = __builtin_fmaf(gv, wv, acc);
+        }
+        const unsigned mw = lmask[(k % 3) * C + c];
+        a.h3[row_of(k) * (196 * C) + (192 + qp) * C + c] = ((mw >> qp) & 1u) ? acc : 0.f;
+    };
+
+    // ---- the roles run separate loops with the same barrier sequence: sg-zero | prologue | one per step ------------
+    if (mrole) {
+        f32x4 A[C / 8];
+        if (has_fwd) stage_row(0);
+        __syncthreads();                                         // sg zeroed, filter fragments in LDS
+        if (has_fwd) {
+            read_frags(A);
+            if (n_my > 1) stage_row(1);
+            fwd(0, A);
+        }
+        __syncthreads();
+        for (int t = 0; t <= n_my; ++t) {
+            if (has_fwd && t + 1 < n_my) {
+                read_frags(A);                                   // row t+1 (staged one step ago)
+                if (t + 2 < n_my) stage_row(t + 2);              // lands during this step
+            }
+            if (has_bwd && t >= 1) bwd(t - 1);
+            if (has_fwd && t + 1 < n_my) fwd(t + 1, A);
+            __syncthreads();
+        }
+    } else {
+        float xv0[4], xv1[4];
+        load_x(0, xv0);
+        stage_left(0);
+        if (n_my > 1) stage_left(1);
+        __syncthreads();
+        left_fwd(0);
+        __syncthreads();
+        auto step = [&](int t, float (&xc)[4], float (&xn)[4]) {
+            if (t >= 1 && gt == 0) finish_loss(t - 1);
+            if (t < n_my) {
+                if (t + 1 < n_my) load_x(t + 1, xn);
+                gather(t, xc);
+            }
+            if (t >= 1) left_bwd(t - 1);
+            if (t + 1 < n_my) left_fwd(t + 1);                   // its image was staged two steps ago
+            if (t + 2 < n_my) stage_left(t + 2);                 // into the buffer left_fwd(t) read in the previous step
+            __syncthreads();
+        };
+        for (int t = 0; t <= n_my; t += 2) {
+            step(t, xv0, xv1);
+            if (t + 1 <= n_my) step(t + 1, xv1, xv0);
+        }
+    }
+}
+
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
     if (a.pipe && a.do_backward && a.C == 64 && a.n_rows >= 2 * a.pipe) {
         constexpr int C = 64;
         const int lds = (2 * 224 * MN_NKP + 2 * MN_GR * MN_GWP + 2 * 224 * (C / 32) + 8 + (C / 8) * 256 + 13 * 64 * (C / 32)) * 4 + 8 * 32 * C * 4;
         static PerDeviceOnce attr;
-        if (attr.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((mnist_tail_pipe_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
+        if (attr.need()) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        }
+        if (a.pipe_version == 2) hipLaunchKernelGGL((mnist_tail_pipe2_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
+        else hipLaunchKernelGGL((mnist_tail_pipe_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
         return;
     }
     const int lds = (224 * MN_NKP + MN_GR * MN_GWP + 224 * (a.C / 32) + 4) * 4;

@@ -173,9 +173,12 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "latent_turn"      1 (default): Linear backward / forward on the weight-stationary kernels (dg_linear.hip) where the shapes
  *                      allow; 0: on the position-batched kernel like every other layer.  "lin_groups_fwd" / "lin_groups_bwd":
  *                      their workgroups per column tile / K slice (0 = from the CU count)
- *   "graph_max_rows"   call shapes of at most this many latent rows (default 1024) replay a captured hipGraph of the L-step loop
- *                      instead of enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum);
- *                      never while the caller's stream is itself capturing); 0 = always enqueue
+ *   "graph_max_rows"   > 0: call shapes of at most this many latent rows replay a captured hipGraph of the L-step loop instead of
+ *                      enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum); never while
+ *                      the caller's stream is itself capturing).  Default 0 = always enqueue: measured no gain at the reference's
+ *                      default batch (500 rows: 780 vs 779 img/s), and on ROCm 7.2 a graph the CALLER captured of a call on the same
+ *                      handle replays wrongly after an internal replay ran in between (tools/graph_interplay_repro.py) -- do not
+ *                      combine the two on one handle
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd_split"   CelebA forward tail (NET_DIM 64): workgroups of the role-split persistent kernel (default 512 = two per CU);
  *                      0 = the per-band kernel (celeba_tail_fwd16_kernel; same y and da6 bit for bit, the per-row loss to rounding)

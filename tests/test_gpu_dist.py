@@ -125,7 +125,7 @@ try:
         gan.prepare(32)
     ids = [None] * world
     dist.all_gather_object(ids, gan.tuning_id())
-    x = np.asarray(gan.generate(synth.make_z(N, 128, seed=4)).cpu())
+    x = np.asarray(gan.generate(synth.make_z(N, 128, seed=4)))
     x = synth.adversarial(x, 0.3, 0.0, 1.0, seed=5)
     clf = nb.model_a(nb_filters=8)
     clf._device = gpu

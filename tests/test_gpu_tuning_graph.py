@@ -80,12 +80,12 @@ def test_tuning_cache_file_hands_the_choice_to_the_next_process(tmp_path):
 
 @pytest.mark.parametrize("arch,B,R,L", [("mnist", 24, 5, 6), ("mnist", 50, 10, 4), ("celeba", 6, 10, 3)])
 def test_replayed_loop_graph_reproduces_the_enqueued_launches(arch, B, R, L):
-    """Call shapes of at most graph_max_rows latent rows replay a captured graph of the L-step loop (images staged into the
+    """(Opt-in.)  Call shapes of at most graph_max_rows latent rows replay a captured graph of the L-step loop (images staged into the
     engine's own buffer): same kernels, same arguments -> bit-identical to enqueuing them, for new images through the same
     graph, for seeded latents, and after an option change rebuilt the graph."""
-    g1, p = make_gan(arch, rec_rr=R, rec_iters=L)              # default: graph for <= 1024 rows
+    g1, p = make_gan(arch, rec_rr=R, rec_iters=L)
+    g1.set_option("graph_max_rows", 1024)                      # opt-in (off by default: include/defensegan_hip.h)
     g0, _ = make_gan(arch, rec_rr=R, rec_iters=L)
-    g0.set_option("graph_max_rows", 0)
     for seed in (3, 5):
         x = g1.generate(g1.init_latents(B, seed=seed)).contiguous()
         z0 = g1.init_latents(B * R, seed=seed + 1)
