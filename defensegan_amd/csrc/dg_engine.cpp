@@ -166,7 +166,7 @@ struct dg_handle {
     int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
                                    // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
-    int tail_pipe_version = 2;     // 2 = mnist_tail_pipe2_kernel, 1 = mnist_tail_pipe_kernel (dg_tail_mfma.hip)
+    int tail_pipe_version = 3;     // mnist_tail_pipe3_kernel / _pipe2_ / _pipe_kernel (dg_tail_mfma.hip)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
     // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
@@ -890,14 +890,16 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.C = last.cin;
         t.do_backward = tail_backward ? 1 : 0;
         t.pipe = h->tail_pipe;
-        t.pipe_version = h->tail_pipe_version;
+        t.want_loss = want_loss ? 1 : 0;
+        // the third-generation kernel leaves the per-row loss alone: a launch whose loss is read (dg_loss_grad) runs the first
+        t.pipe_version = (h->tail_pipe_version == 3 && want_loss) ? 1 : h->tail_pipe_version;
 #ifdef DG_MEASURE
         t.dbg = h->tail_dbg;
         t.trace = h->d_tail_trace;
 #endif
         const double macs = 67.0 * 67.0 * last.cin;   // valid taps 14 -> 28
         const bool piped = t.pipe > 0 && tail_backward && t.C == 64 && n_rows >= 2 * t.pipe;   // launch_mnist_tail_mfma
-        ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? (t.pipe_version == 2 ? "T5fb@mnist_tail_pipe2_kernel" : "T5fb@mnist_tail_pipe_kernel") : "T5fb@mnist_tail_mfma_kernel",
+        ProfScope ps(h, s, prof, !tail_backward ? "T5f@mnist_tail_mfma_kernel" : piped ? (t.pipe_version == 3 ? "T5fb@mnist_tail_pipe3_kernel" : t.pipe_version == 2 ? "T5fb@mnist_tail_pipe2_kernel" : "T5fb@mnist_tail_pipe_kernel") : "T5fb@mnist_tail_mfma_kernel",
                      (tail_backward ? 4.0 : 2.0) * macs * n_rows);
         dg::launch_mnist_tail_mfma(t, s);
     }
@@ -1643,7 +1645,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "tail_pipe_version") {
-        if (atoi(value) != 1 && atoi(value) != 2) return fail(DG_E_INVALID, "tail_pipe_version: 1 or 2");
+        if (atoi(value) < 1 || atoi(value) > 3) return fail(DG_E_INVALID, "tail_pipe_version: 1, 2 or 3");
         h->tail_pipe_version = atoi(value);
         return DG_OK;
     }

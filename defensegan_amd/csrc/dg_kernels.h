@@ -121,7 +121,9 @@ struct MnistTailArgs {
     int C;               // net_dim (64)
     int do_backward;
     int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
-    int pipe_version;    // 2: mnist_tail_pipe2_kernel (matrix work levelled over the SIMDs, positions 192..195 on the gather waves); 1: mnist_tail_pipe_kernel
+    int want_loss;       // 0: nobody reads this launch's per-row loss (every launch of a projection but the last forward): the third-
+                         // generation pipelined kernel, which does not reduce it, may run
+    int pipe_version;    // 3: mnist_tail_pipe3_kernel (one GEMM per wave, 16 waves; no loss); 2: mnist_tail_pipe2_kernel (matrix work levelled over the SIMDs, positions 192..195 on the gather waves); 1: mnist_tail_pipe_kernel
 #ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
     long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr

@@ -181,7 +181,7 @@ __device__ __forceinline__ void tail_fwd_compute_ldsw(const f32x4 (&a)[C / 8], i
     }
 }
 
-template <int C, int COUT, int GWP>
+template <int C, int COUT, int GWP, int NBATCH = 3>
 __device__ __forceinline__ void tail_bwd_tile_ldsw(const float* sg, int gbase, bool valid, const float* sWb, f32x16 (&acc)[C / 32], int lane) {
     constexpr int NK = 25 * COUT, NS = (NK + 1) / 2, U = C / 32;
     const int fh = lane >> 5;
@@ -191,8 +191,9 @@ __device__ __forceinline__ void tail_bwd_tile_ldsw(const float* sg, int gbase, b
         for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
     // The operand reads are issued in three batches, each waited for once: left to itself hipcc sinks every read to its use
     // (ds_read; s_waitcnt lgkmcnt(0); mfma -- 2 * NS exposed LDS round trips per tile, 2/3 of this phase's time).  Bigger
-    // batches need more registers than the pipelined kernel (at its 168-VGPR cap) has: two batches already spill.
-    constexpr int BATCH = (NS + 2) / 3;
+    // batches need more registers than the pipelined kernel (at its 168-VGPR cap) has: two batches already spill.  (The
+    // third-generation kernel's backward waves hold nothing else: one batch, NBATCH = 1.)
+    constexpr int BATCH = (NS + NBATCH - 1) / NBATCH;
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0 += BATCH) {
         float gv[BATCH];
@@ -914,6 +915,334 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe2_kernel(MnistTailArgs a) 
     }
 }
 
+// ---- pipelined variant, third generation: ONE GEMM per wave ------------------------------------------------------------
+// mnist_tail_pipe2_kernel levelled the MFMAs over the SIMDs and the step stayed as long (65.5 vs 66.6 us): what bounds a step is
+// not the matrix pipe but the dependent chain inside the waves that run BOTH GEMMs of a tile one after the other (wait for the
+// DMA, read fragments, issue the next DMA, gather + multiply + mask + transpose + store the backward tile, ballots + multiply +
+// write P: ~11 k cycles).  Here the workgroup has 16 waves and every GEMM of a row has a wave of its own:
+//   waves 0-5    forward GEMM of tile w (stage, fragments, ReluGrad bits, P)
+//   waves 6-11   backward GEMM of tile w-6 (masked tile through a private 4 KB scratch, row stores)
+//   waves 12-15  gather / sigmoid / loss and the 4 positions 192..195 (as in pipe2)
+// so the longest chain in a step is one GEMM (or the gather).  ReluGrad bits are kept for three rows (written for row t+1 while
+// read for row t-1), everything else as in pipe2; 128 VGPRs per wave (4 waves per SIMD).
+// The second-generation text follows.
+// ---- (second generation) the matrix work levelled over the four SIMDs
+// In mnist_tail_pipe_kernel wave w < 7 owns position tile w for both GEMMs: waves (0,4), (1,5), (2,6) share a SIMD, so three
+// SIMDs carry two tiles = 116 MFMAs per step (7.4 k cycles of matrix pipe) and the fourth one tile -- and tile 6 is 4 real
+// positions (192..195) padded to 32.  The M waves are the step's critical path (~11 k of 13 k cycles, tools/tail_trace_mnist.py),
+// mostly waiting for each other's MFMAs.  Here
+//   waves 0-3   forward + backward of tile w                     (58 MFMAs)
+//   waves 4, 5  forward of tile w only                           (32)
+//   waves 6, 7  backward of tiles 4, 5 (masks, da5 image and filter fragments are in LDS: any wave can do it; the masked
+//               tile goes through a 4 KB scratch in the wave's own, otherwise unused staging region)          (26)
+//   the 4 positions of "tile 6" leave the matrix pipe: the gather waves compute their 4 x 25 P entries, their ReluGrad bits and
+//   their 4 x 64 gradients with v_fma chains in the MFMA's k order (bit-identical: an MFMA is a k-ordered fma chain), from a
+//   1 KB image one of them stages by LDS-DMA two rows ahead
+// so every SIMD carries 84-90 MFMAs per step (5.8 k cycles) and no MFMA is spent on padding rows.  Same barrier sequence, same
+// buffers and the same arithmetic per element as mnist_tail_pipe_kernel (tests/test_gpu_variants.py: bit-identical).
+template <int C>
+__global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a) {
+    static_assert(C == 64, "64 channels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int PSZ = 196 * MN_NKP, GSZ = MN_GR * MN_GWP;
+    float* sP = reinterpret_cast<float*>(smem);                  // [2][196][MN_NKP]
+    float* sg = sP + 2 * PSZ;                                    // [2][31][32]
+    unsigned* xmask = reinterpret_cast<unsigned*>(sg + 2 * GSZ); // [3][6 tiles][C] ReluGrad bits by row % 3
+    float* sred = reinterpret_cast<float*>(xmask + 3 * 6 * C);   // [2][4]
+    float* sWf = sred + 8;                                       // forward filter fragments [C/8][64][4]
+    float* sWb = sWf + (C / 8) * 256;                            // backward filter fragments [13][64][C/32]
+    char* stages = reinterpret_cast<char*>(sWb + 13 * 64 * (C / 32));     // [6 forward waves][8 KB], then [6 backward waves][4 KB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const bool mrole = wave < 12;
+    const bool has_fwd = wave < 6;                               // forward GEMM of tile `wave`
+    const bool has_bwd = wave >= 6 && wave < 12;                 // backward GEMM of tile wave - 6
+    const int tile = wave;                                       // forward tile
+    const int btile = wave - 6;                                  // backward tile
+    char* stage = stages + (wave < 6 ? wave : 0) * (32 * C * 4); // waves 0-5: A tile [32][C], LDS-DMA target
+    float* scratch = reinterpret_cast<float*>(stages + 6 * (32 * C * 4) + (has_bwd ? btile : 0) * 4096);
+    float* la = reinterpret_cast<float*>(stages + 6 * (32 * C * 4) + 6 * 4096);   // [2][4 positions][C] images of positions 192..195
+    unsigned* lmask = reinterpret_cast<unsigned*>(la + 2 * 4 * C);                // [3][C] ReluGrad bits of 192..195, by row % 3
+    const int gt = tid - 768;                                    // gather thread id (G waves)
+    const int gw = wave - 12;
+    const int n_my = ((int)a.n_rows - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    auto row_of = [&](int k) { return (long long)blockIdx.x + (long long)k * gridDim.x; };
+
+    for (int i = tid; i < 2 * GSZ; i += 1024) sg[i] = 0.f;       // zero borders of both da5 images, written once
+    for (int i = tid; i < (C / 8) * 256; i += 1024) {
+        const int e = i & 3, l = (i >> 2) & 63, kk = i >> 8;
+        const int kappa = l & 31, c = kk * 8 + (l >> 5) * 4 + e;
+        sWf[i] = kappa < 25 ? a.F5[kappa * C + c] : 0.f;
+    }
+    for (int i = tid; i < 13 * 64 * (C / 32); i += 1024) {
+        const int u = i % (C / 32), l = (i / (C / 32)) & 63, st = i / (64 * (C / 32));
+        const int kappa = 2 * st + (l >> 5);
+        sWb[i] = kappa < 25 ? a.F5[kappa * C + u * 32 + (l & 31)] : 0.f;
+    }
+    const int q = tile * 32 + frow;                              // this lane's position in the forward role (tiles 0-5: always valid)
+    constexpr int CH = C / 4;                                    // 16-B chunks per position
+    constexpr int NI = 32 * CH / 64;                             // DMA instructions per tile
+    auto stage_row = [&](int k) {
+        const char* src = reinterpret_cast<const char*>(a.h3 + row_of(k) * (196 * C) + (long long)tile * 32 * C);
+#pragma unroll
+        for (int qi = 0; qi < NI; ++qi) {
+            const int slot = qi * 64 + lane;
+            const int pos = slot / CH, c = slot % CH;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + pos * (C * 4) + ((c ^ (pos & (CH - 1))) << 4)),
+                (__attribute__((address_space(3))) void*)(stage + qi * 1024), 16, 0, 0);
+        }
+    };
+    auto read_frags = [&](f32x4 (&av)[C / 8]) {          // (the stage landed before the barrier that ended the previous step)
+#pragma unroll
+        for (int kk = 0; kk < C / 8; ++kk)
+            av[kk] = *reinterpret_cast<const f32x4*>(stage + frow * (C * 4) + (((kk * 2 + fh) ^ (frow & (CH - 1))) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto fwd = [&](int k, const f32x4 (&av)[C / 8]) {
+        unsigned* mk = xmask + ((k % 3) * 6 + tile) * C;
+        int word = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long bal = __ballot(av[kk][e] > 0.f);
+                lo[e] = __builtin_amdgcn_readfirstlane((unsigned)bal);
+                hi[e] = __builtin_amdgcn_readfirstlane((unsigned)(bal >> 32));
+            }
+            // (a v_cmp result SGPR is not safe as the data operand of a v_writelane issued right behind it on gfx950: 4 wait states)
+            asm volatile("s_nop 3\n\t"
+                         "v_writelane_b32 %0, %1, %9\n\tv_writelane_b32 %0, %2, %10\n\t"
+                         "v_writelane_b32 %0, %3, %11\n\tv_writelane_b32 %0, %4, %12\n\t"
+                         "v_writelane_b32 %0, %5, %13\n\tv_writelane_b32 %0, %6, %14\n\t"
+                         "v_writelane_b32 %0, %7, %15\n\tv_writelane_b32 %0, %8, %16"
+                         : "+v"(word)
+                         : "s"(lo[0]), "s"(lo[1]), "s"(lo[2]), "s"(lo[3]), "s"(hi[0]), "s"(hi[1]), "s"(hi[2]), "s"(hi[3]),
+                           "i"(8 * kk), "i"(8 * kk + 1), "i"(8 * kk + 2), "i"(8 * kk + 3),
+                           "i"(8 * kk + 4), "i"(8 * kk + 5), "i"(8 * kk + 6), "i"(8 * kk + 7));
+        }
+        mk[lane] = (unsigned)word;
+        tail_fwd_compute_ldsw<C>(av, tile * 32, sWf, sP + (k & 1) * PSZ, MN_NKP, lane);
+    };
+    auto bwd = [&](int k) {
+        const unsigned* mk = xmask + ((k % 3) * 6 + btile) * C;
+        float* hrow = a.h3 + row_of(k) * (196 * C);
+        const int qq = btile * 32 + frow;                        // tiles 0-5: every position exists
+        const int oh = qq / 14, ow = qq - oh * 14;
+        f32x16 acc[C / 32];
+        tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, (2 * oh) * MN_GWP + 2 * ow, true, sWb, acc, lane);
+        float* tb = scratch;                                     // private 4 KB: the P tile of this parity is being rewritten by the forward wave
+        const int er = lane >> 3, ec = (lane & 7) * 4;
+#pragma unroll
+        for (int u = 0; u < C / 32; ++u) {
+            const unsigned mw = mk[u * 32 + frow];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pr = (e & 3) + 8 * (e >> 2) + 4 * fh;
+                tb[pr * 32 + frow] = ((mw >> pr) & 1u) ? acc[u][e] : 0.f;
+            }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int qr = btile * 32 + p * 8 + er;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
+                *reinterpret_cast<f32x4*>(hrow + qr * C + u * 32 + ec) = v;
+            }
+        }
+    };
+    const float bias = a.b5[0];
+    const float gscale = 2.0f / 784.0f;
+    // ---- gather: the 784 output pixels by PARITY CLASS.  Pixel (i, j) = (2u + a, 2v + b) has 2 (a = 0: kh 1, 3) or 3 (a = 1:
+    // kh 0, 2, 4) filter rows and likewise columns: 4 / 6 / 6 / 9 terms.  Every gather wave takes 49 pixels (u, v) of each of
+    // the four classes, one class per round, so a round reads exactly the terms that exist (25 LDS reads per thread and step
+    // instead of 4 x 9 with a zero pad entry for the missing ones -- the trace had the gather waves as the step's critical
+    // path); the terms are added in ascending (kh, kw) as everywhere else, so every pre-activation, hence y and da5, is bit-identical
+    // to the other tail kernels'.  This kernel does NOT reduce the per-row loss: the projection loop never reads it (the launch
+    // that needs it -- the last forward, dg_loss_grad -- runs a kernel that does, MnistTailArgs.want_loss).
+    const int gq = gw * 49 + (lane < 49 ? lane : 48);             // (u, v) index of this lane, 0..195
+    const int gu = gq / 14, gv = gq - gu * 14;
+    auto load_x = [&](int k, float (&xv)[4]) {
+        const float* xrow = a.x + (long long)((unsigned)row_of(k) / (unsigned)a.R) * 784;     // rows < 2^24: 32-bit division
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) xv[cls] = xrow[(2 * gu + (cls >> 1)) * 28 + 2 * gv + (cls & 1)];
+    };
+    auto gather = [&](int k, const float (&xv)[4]) {
+        const float* pP = sP + (k & 1) * PSZ;
+        float* pg = sg + (k & 1) * GSZ;
+        // a term whose input position does not exist (image border) reads the zero pad entry P[0][31] as before
+        float tv[25];
+        int nt = 0;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int pa = cls >> 1, pb = cls & 1;
+#pragma unroll
+            for (int ah = 0; ah < 2 + pa; ++ah) {
+                const int kh = (1 - pa) + 2 * ah;
+                const int oh = gu + ((pa + 1 - kh) >> 1);          // (i + 1 - kh) / 2 with i = 2u + a
+                const bool okh = oh >= 0 && oh < 14;
+#pragma unroll
+                for (int aw = 0; aw < 2 + pb; ++aw) {
+                    const int kw = (1 - pb) + 2 * aw;
+                    const int ow = gv + ((pb + 1 - kw) >> 1);
+                    const bool ok = okh && ow >= 0 && ow < 14;
+                    tv[nt++] = pP[ok ? (oh * 14 + ow) * MN_NKP + kh * 5 + kw : 31];
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 25; ++t) asm volatile("" : "+v"(tv[t]));
+        nt = 0;
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int pa = cls >> 1, pb = cls & 1;
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < (2 + pa) * (2 + pb); ++t) sacc += tv[nt++];
+            const float y = 1.0f / (1.0f + expf(-(sacc + bias)));
+            const float d = y - xv[cls];
+            if (lane < 49) pg[(2 * gu + pa + 1) * MN_GWP + (2 * gv + pb + 1)] = gscale * d * y * (1.0f - y);
+        }
+    };
+    // ---- positions 192..195 on the gather waves (plain fma chains in the MFMA's k order) ---------------------------------
+    auto stage_left = [&](int k) {        // forward wave 5: 4 positions x C floats = 1 KB, contiguous in h3
+        if (wave != 5) return;
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(a.h3 + row_of(k) * (196 * C) + 192 * C + lane * 4),
+            (__attribute__((address_space(3))) void*)(la + (k & 1) * (4 * C)), 16, 0, 0);
+    };
+    // (run by the FORWARD waves after their GEMM: the trace showed the gather waves as the step's critical path -- 10.9 k cycles with
+    // this work against 5.3 k for a forward wave; lt = thread index inside the group of waves that shares the piece)
+    auto left_fwd = [&](int k, int lt) {
+        const float* A = la + (k & 1) * (4 * C);
+        if (lt < C) {                     // ReluGrad bits of the 4 positions, one word per channel (bit p = position 192 + p)
+            unsigned w = 0;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) w |= (A[p * C + lt] > 0.f ? 1u : 0u) << p;
+            lmask[(k % 3) * C + lt] = w;
+        }
+        if (lt < 100) {                   // P[192 + qp][kappa] = sum_c h[c] F[kappa][c], c in the order of the MFMA k-steps
+            const int qp = lt / 25, kappa = lt - qp * 25;
+            // (measured: fetching the operands in one or two batches, each waited for once, made this piece SLOWER -- 9.7 k vs 8.7 k
+            // cycles for the wave's step, the bursts queue behind the GEMM waves' LDS traffic; one k-step at a time it is)
+            float acc = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < C / 8; ++kk) {
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(A + qp * C + kk * 8);
+                const f32x4 h1 = *reinterpret_cast<const f32x4*>(A + qp * C + kk * 8 + 4);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + kappa) * 4);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + 32 + kappa) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc = __builtin_fmaf(h0[e], w0[e], acc);
+                    acc = __builtin_fmaf(h1[e], w1[e], acc);
+                }
+            }
+            sP[(k & 1) * PSZ + (192 + qp) * MN_NKP + kappa] = acc;
+        }
+    };
+    auto left_bwd = [&](int k, int lt) {  // dH[192 + qp][c] = sum_kappa G[kappa] F[kappa][c], kappa ascending (the MFMA k order)
+        const int qp = lt >> 6, c = lt & 63;
+        const float* pg = sg + (k & 1) * GSZ + (2 * 13) * MN_GWP + 2 * (10 + qp);      // position 192 + qp = (oh 13, ow 10 + qp)
+        float acc = 0.f;
+#pragma unroll
+        for (int kappa = 0; kappa < 25; ++kappa) {
+            const float gv = pg[(kappa / 5) * MN_GWP + (kappa % 5)];
+            const float wv = sWb[((kappa >> 1) * 64 + (kappa & 1) * 32 + (c & 31)) * (C / 32) + (c >> 5)];
+            acc = __builtin_fmaf(gv, wv, acc);
+        }
+        const unsigned mw = lmask[(k % 3) * C + c];
+        a.h3[row_of(k) * (196 * C) + (192 + qp) * C + c] = ((mw >> qp) & 1u) ? acc : 0.f;
+    };
+
+    // ---- the roles run separate loops with the same barrier sequence: sg-zero | prologue | one per step ------------
+    (void)mrole;
+    // Barriers are LDS-only (lds_barrier: lgkmcnt(0) + s_barrier).  __syncthreads() would also wait for vmcnt(0), i.e. for the
+    // acknowledgement of every row store a backward wave has just issued -- nobody in this kernel reads them, and their latency
+    // then sits on every step's critical path.  The only global -> LDS traffic a barrier has to publish are the LDS-DMAs of the
+    // forward waves, issued at the START of a step and waited for (long landed) right before the barrier that ends it.
+    auto dma_landed_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); lds_barrier(); };
+#ifdef DG_MEASURE
+    // phase stamps (tools/tail_trace_mnist.py): per role, cycles between the barriers (work) and inside them (wait), steps 2 .. n-3
+    const bool tr = DG_TRACE_PTR(a) != nullptr && lane == 0 && (wave == 0 || wave == 3 || wave == 6 || wave == 12) && blockIdx.x < 2048;
+    long long tw = 0, tb = 0, tc0 = 0, tc1 = 0;
+    int tn = 0;
+#define TR_BEGIN() do { if (tr) tc0 = (long long)__builtin_readcyclecounter(); } while (0)
+#define TR_MID() do { if (tr) tc1 = (long long)__builtin_readcyclecounter(); } while (0)
+#define TR_END(t) do { if (tr && (t) >= 2 && (t) + 2 < n_my) { tw += tc1 - tc0; tb += (long long)__builtin_readcyclecounter() - tc1; ++tn; } } while (0)
+#define TR_FLUSH(slot) do { if (tr) { long long* o = DG_TRACE_PTR(a) + (long long)blockIdx.x * 16 + (slot) * 3; o[0] = tw; o[1] = tb; o[2] = tn; } } while (0)
+#else
+#define TR_BEGIN() do {} while (0)
+#define TR_MID() do {} while (0)
+#define TR_END(t) do {} while (0)
+#define TR_FLUSH(slot) do {} while (0)
+#endif
+    if (has_fwd) {
+        // (a loop per role: with both GEMMs in one loop body the forward wave's fragments stay live across the backward code it
+        // never runs, and the kernel does not fit the 128 VGPRs of four waves per SIMD)
+        f32x4 A[C / 8];
+        stage_row(0);
+        stage_left(0);
+        dma_landed_barrier();                                    // sg zeroed, filter fragments in LDS, row 0 staged
+        read_frags(A);
+        if (n_my > 1) { stage_row(1); stage_left(1); }
+        fwd(0, A);
+        if (wave < 2) left_fwd(0, tid);
+        dma_landed_barrier();
+        for (int t = 0; t <= n_my; ++t) {
+            TR_BEGIN();
+            if (t + 1 < n_my) {
+                read_frags(A);                                   // row t+1 (staged one step ago)
+                if (t + 2 < n_my) { stage_row(t + 2); stage_left(t + 2); }     // land during this step
+                fwd(t + 1, A);
+            }
+            // positions 192..195: waves 0, 1 their forward entries of row t+1, waves 2-5 their gradients of row t-1
+            if (wave < 2) { if (t + 1 < n_my) left_fwd(t + 1, tid); }
+            else if (t >= 1) left_bwd(t - 1, tid - 128);
+            TR_MID();
+            dma_landed_barrier();
+            TR_END(t);
+        }
+        TR_FLUSH(wave == 0 ? 0 : 3);
+    } else if (has_bwd) {
+        lds_barrier();
+        lds_barrier();
+        for (int t = 0; t <= n_my; ++t) {
+            TR_BEGIN();
+            if (t >= 1) bwd(t - 1);
+            TR_MID();
+            lds_barrier();                                       // the row stores stay in flight
+            TR_END(t);
+        }
+        TR_FLUSH(1);
+    } else {
+        float xv0[4], xv1[4];
+        load_x(0, xv0);
+        lds_barrier();
+        lds_barrier();
+        auto step = [&](int t, float (&xc)[4], float (&xn)[4]) {
+            TR_BEGIN();
+            if (t < n_my) {
+                if (t + 1 < n_my) load_x(t + 1, xn);
+                gather(t, xc);
+            }
+            TR_MID();
+            lds_barrier();
+            TR_END(t);
+        };
+        for (int t = 0; t <= n_my; t += 2) {
+            step(t, xv0, xv1);
+            if (t + 1 <= n_my) step(t + 1, xv1, xv0);
+        }
+        TR_FLUSH(2);
+    }
+#undef TR_BEGIN
+#undef TR_MID
+#undef TR_END
+#undef TR_FLUSH
+}
+
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
     if (a.pipe && a.do_backward && a.C == 64 && a.n_rows >= 2 * a.pipe) {
         constexpr int C = 64;
@@ -923,7 +1252,13 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
-        if (a.pipe_version == 2) hipLaunchKernelGGL((mnist_tail_pipe2_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
+        if (a.pipe_version == 3) {
+            const int lds3 = (2 * 196 * MN_NKP + 2 * MN_GR * MN_GWP + 3 * 6 * C + 8 + (C / 8) * 256 + 13 * 64 * (C / 32)) * 4 + 6 * 32 * C * 4 + 6 * 4096 +
+                             2 * 4 * C * 4 + 3 * C * 4;
+            static PerDeviceOnce attr3;
+            if (attr3.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+            hipLaunchKernelGGL((mnist_tail_pipe3_kernel<64>), dim3(a.pipe), dim3(1024), lds3, s, a);
+        } else if (a.pipe_version == 2) hipLaunchKernelGGL((mnist_tail_pipe2_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
         else hipLaunchKernelGGL((mnist_tail_pipe_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);
         return;
     }

@@ -79,6 +79,7 @@ def _run(gan, x, z0):
 
 BITWISE = {
     "mnist": [{"tail_pipe": 0}, {"tail_pipe": 100}, {"tail_pipe_version": 1}, {"tail_pipe_version": 1, "tail_pipe": 100},
+              {"tail_pipe_version": 3}, {"tail_pipe_version": 3, "tail_pipe": 100}, {"tail_pipe_version": 3, "tail_pipe": 37},
               {"tail_pipe": 37}, {"two_streams": 2, "two_stream_min_rows": 64},
               {"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01, "jobs.min_level": 0}, {"jobs.min_level": 1},
               {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300},
