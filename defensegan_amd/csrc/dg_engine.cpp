@@ -76,6 +76,7 @@ struct JobList {
     int xcd_order = 0;             // 1 = head of the list re-arranged for XCD locality (dg_plan.h order_for_xcd)
     int snake = 0;                 // 1 = every other round of #CUs jobs reversed (boustrophedon)
     double slack = 0.0;            // the cutting threshold the list was built with (dg_plan.h build_jobs)
+    double taper = 0.0;            // JobModel::taper the list was built with
     double xcd_head = 0.0;         // head fraction of the XCD-locality order
     double predicted_us = 0.0;     // simulated makespan of the cost model
     double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
@@ -149,6 +150,7 @@ struct dg_handle {
     int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
+    int job_taper_tune = 1;        // 1 = tapered lists (dg_plan.h JobModel::taper) are among the timed candidates
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
     // launch took the same time (465 vs 466 us), fetched the same bytes across the L2/fabric boundary (907 vs 910 MB raw) and
@@ -507,10 +509,14 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
     std::vector<Cand> cands;
     const int n_levels = 3;
     const bool tune = h->job_tune && h->job_slack <= 0.0 && A && Out;
-    const double slacks_tune[] = {1e30, 0.85, 0.92, 0.97, 1.0, 1.04, 1.1};
+    // (slack, taper) pairs offered to the timing: the cutting thresholds as before, plus tapered lists (dg_plan.h JobModel::taper)
+    const double slacks_tune[] = {1e30, 0.85, 0.92, 0.97, 1.0, 1.04, 1.1, 1e30, 1e30, 1e30, 1.0, 1.0, 1.0};
+    const double tapers_tune[] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.65, 0.8, 0.5, 0.65, 0.8};
     const double slack_one[] = {h->job_slack};
+    const double taper_one[] = {h->job_model.taper};
     const double* slacks = tune ? slacks_tune : slack_one;
-    const int n_slacks = tune ? 7 : 1;
+    const double* tapers = tune ? tapers_tune : taper_one;
+    const int n_slacks = tune ? (h->job_taper_tune ? 13 : 7) : 1;
     for (int lvl = 0; lvl < n_levels; ++lvl) {
         if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
         for (int k = 0; k < n_slacks; ++k) {
@@ -518,8 +524,11 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             c.jl.n_rows = n_rows;
             c.jl.min_level = lvl;
             c.jl.slack = slacks[k];
+            c.jl.taper = tapers[k];
+            dg::JobModel jm = h->job_model;
+            jm.taper = tapers[k];
             c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
-                                    h->job_model, &c.jl.predicted_us, lvl);
+                                    jm, &c.jl.predicted_us, lvl);
             auto add = [&](Cand&& x) {
                 for (const Cand& o : cands)
                     if (o.jl.min_level == x.jl.min_level && o.jobs.size() == x.jobs.size() &&
@@ -632,9 +641,10 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             cands[best].jl.measured_us = cands[best].ms * 1e3;
             if (getenv("DG_TUNE_VERBOSE")) {
                 for (size_t i = 0; i < cands.size(); ++i)
-                    fprintf(stderr, "[dg tune] %s rows %d level %d%s jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(), n_rows,
-                            cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", (int)cands[i].jobs.size(),
-                            cands[i].jl.predicted_us, cands[i].ms * 1e3, i == best ? "  <- kept" : "");
+                    fprintf(stderr, "[dg tune] %s rows %d level %d%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake ? " snake" : "      ",
+                            cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
+                            i == best ? "  <- kept" : "");
             }
         }
         for (size_t i = 0; i < cands.size(); ++i)
@@ -1486,7 +1496,7 @@ int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
         for (const JobList& jl : op.jobs) {
             dg::TuneRecord r;
             r.op = op.name; r.n_rows = jl.n_rows; r.min_level = jl.min_level; r.slack = jl.slack; r.snake = jl.snake;
-            r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us;
+            r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us; r.taper = jl.taper;
             out += dg::format_tune_record(r);
         }
     };
@@ -1528,7 +1538,7 @@ int dg_import_tuning(dg_handle* h, const char* text) {
             return fail(DG_E_INVALID, "tuning record for unknown layer '%s' / bad row count %d / level %d", r.op.c_str(), r.n_rows, r.min_level);
         JobList jl;
         jl.n_rows = r.n_rows; jl.min_level = r.min_level; jl.slack = r.slack; jl.snake = r.snake; jl.xcd_order = r.xcd_order;
-        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us;
+        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper;
         const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(op->bplan, op->family, h->cu_count, h->job_slots_per_cu[op->family][r.min_level],
                                                                    r, h->job_model, &jl.predicted_us);
         if ((int)jobs.size() != r.n_jobs)
@@ -1661,7 +1671,8 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
-        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head") {
+        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
+        k == "jobs.taper_tune") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1671,6 +1682,8 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.min_level") h->job_min_level = (int)v;
         else if (k == "jobs.tune") h->job_tune = v != 0.0;
         else if (k == "jobs.xcd_head") h->job_xcd_head = v;
+        else if (k == "jobs.taper") h->job_model.taper = v;
+        else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
         drop_job_lists(h);

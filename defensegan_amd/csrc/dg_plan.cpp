@@ -232,7 +232,10 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         Piece pc = pool.top();
         pool.pop();
         const double t0 = free_at.top();
-        if (t0 + pc.us > target && pc.level < max_level) {
+        const double ideal = total / slots;
+        const bool late = model.taper > 0.0 && pc.level < max_level &&
+                          t0 > (pc.level == 0 ? model.taper : 0.5 * (model.taper + 1.0)) * ideal;
+        if ((t0 + pc.us > target || late) && pc.level < max_level) {
             // cut in two: along M while the next level is lower, else along N
             const int nl = pc.level + 1;
             const int bm = shape_bm(family, nl), bn = shape_bn(family, nl);
@@ -299,8 +302,8 @@ void snake_order(std::vector<JobDesc>& jobs, int cus) {
 
 std::string format_tune_record(const TuneRecord& r) {
     char line[256];
-    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
-             r.xcd_head, r.n_jobs, r.measured_us);
+    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f %.17g\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
+             r.xcd_head, r.n_jobs, r.measured_us, r.taper);
     return line;
 }
 
@@ -314,6 +317,13 @@ bool parse_tune_record(const char** pp, TuneRecord* r) {
     if (sscanf(p, "%31s %d %d %lf %d %d %lf %d %lf%n", name, &t.n_rows, &t.min_level, &t.slack, &t.snake, &t.xcd_order, &t.xcd_head,
                &t.n_jobs, &t.measured_us, &used) != 9 || used <= 0)
         return false;
+    {   // optional tenth field on the same line: the taper
+        const char* q = p + used;
+        while (*q == ' ' || *q == '\t') ++q;
+        int u2 = 0;
+        double tp = 0.0;
+        if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%lf%n", &tp, &u2) == 1 && u2 > 0) { t.taper = tp; used = (int)(q - p) + u2; }
+    }
     t.op = name;
     *r = t;
     *pp = p + used;
@@ -322,7 +332,9 @@ bool parse_tune_record(const char** pp, TuneRecord* r) {
 
 std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus, int slots_per_cu, const TuneRecord& r,
                                       const JobModel& model, double* predicted_us) {
-    std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, model, predicted_us, r.min_level);
+    JobModel m = model;
+    m.taper = r.taper;
+    std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);
     if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
     if (r.snake) snake_order(jobs, cus);
     return jobs;

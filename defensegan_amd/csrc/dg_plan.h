@@ -68,6 +68,13 @@ struct JobModel {
     // microseconds of its slot's time (from the K = 128 Linear layer, where they are a third of a job)
     double rate[2][3] = {{141.5, 138.5, 134.0}, {139.0, 136.5, 131.5}};
     double fixed_us[2][3] = {{7.5, 5.0, 3.4}, {7.5, 5.0, 3.4}};
+    // Taper (round 4): real jobs do not run at the model's speed (a workgroup on a CU with fewer neighbours is faster, operands
+    // miss or hit), so where the model sees a level end the CUs finish 3-7 % of the launch apart (tools/job_trace.py: mean last-job
+    // end 273 of 294 us for Generator.2's backward) -- by about a tenth of the duration of the jobs that were started LAST.  With
+    // taper > 0 a piece may only START before taper x (the ideal makespan) at level 0 and before the midpoint between that and
+    // the end at level 1; later it is cut further whatever its predicted end: the launch ends on progressively smaller jobs, and a
+    // mis-predicted speed moves its end by a fraction of a SMALL job.  0 = off.  One more dimension of the timed choice.
+    double taper = 0.0;
 };
 std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, int slots, double slack,
                                 const JobModel& model = JobModel(), double* predicted_us = nullptr, int min_level = 0);
@@ -94,6 +101,7 @@ struct TuneRecord {
     double xcd_head = 0.0;
     int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
     double measured_us = 0.0;  // informational
+    double taper = 0.0;        // JobModel::taper the list was built with (last field of the line; absent in round-4a texts = 0)
 };
 std::string format_tune_record(const TuneRecord& r);                 // one line, '\n'-terminated
 // Parses the record at *p and advances *p behind it; false on a malformed record (nothing consumed) or at the end of the text.

@@ -107,11 +107,12 @@ double dgp2_predicted_us(void* h) { return static_cast<Batched*>(h)->predicted_u
 // Builds the list of (row count, level, threshold, order variant) the way the engine's timing does, keeps it as the current
 // list and writes its record line into `line`; returns the list's length.
 int dgp2_make_recorded(void* h, const char* op, int n_rows, int cus, int slots_per_cu, int min_level, double slack, int snake,
-                       double xcd_head, char* line, int cap) {
+                       double xcd_head, double taper, char* line, int cap) {
     Batched& b = *static_cast<Batched*>(h);
     dg::TuneRecord r;
     r.op = op; r.n_rows = n_rows; r.min_level = min_level; r.slack = slack; r.snake = snake;
     r.xcd_order = xcd_head > 0.0; r.xcd_head = xcd_head;
+    r.taper = taper;
     b.jobs = dg::jobs_from_record(b.plan, b.family, cus, slots_per_cu, r, dg::JobModel(), &b.predicted_us);
     r.n_jobs = (int)b.jobs.size();
     r.measured_us = 123.456;

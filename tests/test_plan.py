@@ -39,7 +39,7 @@ def lib():
     l.dgp2_jobs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp2_apply.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int]
     l.dgp2_make_recorded.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
-                                     C.c_char_p, C.c_int]
+                                     C.c_double, C.c_char_p, C.c_int]
     l.dgp2_rebuild_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
     return l
 
@@ -298,16 +298,17 @@ def test_tuning_records_round_trip_to_the_same_job_lists(lib):
     h, _ = build(lib, "deconv_bwd", 7, 7, 14, 14, 128, 64, 128)          # MNIST Generator.3 backward
     b = lib.dgp2_build(h)
     lines = []
-    variants = [(2560, 0, 1e30, 0, 0.0), (2560, 1, 0.97, 0, 0.0), (2560, 1, 1.04, 1, 0.0), (500, 2, 0.85, 1, 0.0),
-                (2560, 0, 0.0, 0, 0.0), (1280, 1, 1.0, 0, 0.5), (37, 2, 1.1, 0, 0.0)]
+    variants = [(2560, 0, 1e30, 0, 0.0, 0.0), (2560, 1, 0.97, 0, 0.0, 0.0), (2560, 1, 1.04, 1, 0.0, 0.0), (500, 2, 0.85, 1, 0.0, 0.0),
+                (2560, 0, 0.0, 0, 0.0, 0.0), (1280, 1, 1.0, 0, 0.5, 0.0), (37, 2, 1.1, 0, 0.0, 0.0),
+                (2560, 1, 1e30, 0, 0.0, 0.65), (2560, 0, 1.0, 0, 0.0, 0.5)]
     slots = {0: 2, 1: 3, 2: 5}
-    for n_rows, lvl, slack, snake, xhead in variants:
+    for n_rows, lvl, slack, snake, xhead, taper in variants:
         line = C.create_string_buffer(256)
-        n = lib.dgp2_make_recorded(b, b"B3", n_rows, 256, slots[lvl], lvl, slack, snake, xhead, line, 256)
+        n = lib.dgp2_make_recorded(b, b"B3", n_rows, 256, slots[lvl], lvl, slack, snake, xhead, taper, line, 256)
         assert n > 0
         text = line.value.decode()
         f = text.split()
-        assert f[0] == "B3" and int(f[1]) == n_rows and int(f[2]) == lvl and float(f[3]) == slack and int(f[7]) == n
+        assert f[0] == "B3" and int(f[1]) == n_rows and int(f[2]) == lvl and float(f[3]) == slack and int(f[7]) == n and float(f[9]) == taper
         lines.append(text)
         # the record alone rebuilds the list that is current
         assert lib.dgp2_rebuild_matches(b, text.encode(), 0, 256, slots[lvl]) == 1
@@ -319,10 +320,16 @@ def test_tuning_records_round_trip_to_the_same_job_lists(lib):
             assert lib.dgp2_rebuild_matches(b, (" ".join(f2) + "\n").encode(), 0, 256, slots[lvl]) == 0
     # a text of several records: each is found by position; garbage is reported, not skipped
     text = "".join(lines)
-    n_rows, lvl, slack, snake, xhead = variants[-1]
+    n_rows, lvl, slack, snake, xhead, taper = variants[-1]
     assert lib.dgp2_rebuild_matches(b, text.encode(), len(variants) - 1, 256, slots[lvl]) == 1
     assert lib.dgp2_rebuild_matches(b, (text + "B3 what\n").encode(), len(variants), 256, 2) == -1
     assert lib.dgp2_rebuild_matches(b, text.encode(), len(variants), 256, 2) == -1
+    # a text without the tenth field (exported before the taper existed) still parses: taper 0
+    n_rows, lvl, slack, snake, xhead, taper = variants[1]
+    line = C.create_string_buffer(256)
+    lib.dgp2_make_recorded(b, b"B3", n_rows, 256, slots[lvl], lvl, slack, snake, xhead, 0.0, line, 256)
+    old = " ".join(line.value.decode().split()[:9]) + "\n"
+    assert lib.dgp2_rebuild_matches(b, old.encode(), 0, 256, slots[lvl]) == 1
     lib.dgp2_free(b)
     lib.dgp_free(h)
 
@@ -334,3 +341,31 @@ def test_tuning_text_id_ignores_order_and_measured_durations():
     b = head + "B2 2560 1 1 0 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
     c = head + "B2 2560 1 1 1 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
     assert tuning_text_id(a) == tuning_text_id(b) != tuning_text_id(c)
+
+
+def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
+    """JobModel::taper: pieces may only start before taper x the ideal makespan at full size (level 1: before the midpoint to the
+    end); the list is the same work (every output element exactly once, same arithmetic) cut differently -- checked like any list --
+    and its last jobs are small."""
+    rs = np.random.RandomState(5)
+    h, info = build(lib, "deconv_bwd", 4, 4, 7, 7, 128, 32, 128)         # 128 output columns (family 0), K = 32 per tap
+    b = lib.dgp2_build(h)
+    line = C.create_string_buffer(256)
+    n_rows = 700
+    n_plain = lib.dgp2_make_recorded(b, b"B2", n_rows, 16, 3, 1, 1e30, 0, 0.0, 0.0, line, 256)
+    n_taper = lib.dgp2_make_recorded(b, b"B2", n_rows, 16, 3, 1, 1e30, 0, 0.0, 0.5, line, 256)
+    assert n_taper > n_plain                                   # late pieces were cut
+    jobs = (C.c_int * (6 * n_taper))()
+    lib.dgp2_jobs(b, jobs)
+    shapes = np.asarray(jobs).reshape(-1, 6)[:, 1]
+    assert shapes[: n_taper // 4].min() == 1 and shapes[-max(4, n_taper // 10):].min() == 2      # starts whole (level 1), ends on quarters
+    A = rs.standard_normal((n_rows, info["a_rowstride"]))
+    W = rs.standard_normal(25 * 128 * 32)
+    out = np.zeros((n_rows, info["out_rowstride"]))
+    touched = np.zeros(out.shape, np.int32)
+    lib.dgp2_apply(b, A.ctypes.data, W.ctypes.data, np.zeros(1).ctypes.data, out.ctypes.data, touched.ctypes.data, 0)
+    ref = np.zeros_like(out)
+    apply(lib, h, A, W, None, ref, n_rows, 0)
+    assert (touched == 1).all() and np.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    lib.dgp2_free(b)
+    lib.dgp_free(h)

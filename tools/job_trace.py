@@ -31,6 +31,7 @@ gan.reconstruct(x, seed=1)                       # builds / tunes the job lists
 gan.set_option("job_trace", op)
 gan.reconstruct(x, seed=2)
 t = gan.debug_read("job_trace", 65536 * 4 * 2).cpu().numpy().view(np.int64).reshape(-1, 4)
+block = np.nonzero(t[:, 1] > 0)[0]
 t = t[t[:, 1] > 0]
 start, end, hwid, chunks = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
 t0 = start.min()
@@ -59,3 +60,27 @@ prio = ((hwid >> 16) & 3)
 for pr in np.unique(prio):
     m = prio == pr
     print("  slot & 3 = %d: %5d jobs, mean duration per chunk %.3f us" % (pr, m.sum(), (d[m] / np.maximum(chunks[m], 1)).mean()))
+
+# ---- how level is the END of the launch?  per-CU time of its last job's end: a CU that finishes early idles until the launch ends
+xcd = block % 8
+cu_key = xcd * 256 + cu
+fin = np.array([e_us[cu_key == k].max() for k in np.unique(cu_key)])
+busy = np.array([(e_us[cu_key == k] - s_us[cu_key == k]).sum() for k in np.unique(cu_key)])
+print("CUs seen %d; last-job end per CU: mean %.1f us, p10 %.1f, min %.1f, max %.1f (= span)  -> %.1f %% of CU-time idle at the end"
+      % (len(fin), fin.mean(), np.percentile(fin, 10), fin.min(), fin.max(), 100.0 * (1.0 - fin.mean() / fin.max())))
+print("jobs per CU: min %d max %d; sum of job durations per CU: mean %.0f us (p10 %.0f, p90 %.0f)" % (
+    min((cu_key == k).sum() for k in np.unique(cu_key)), max((cu_key == k).sum() for k in np.unique(cu_key)), busy.mean(), np.percentile(busy, 10), np.percentile(busy, 90)))
+# residency-weighted: time during which a CU holds at least 1 / at least 2 jobs
+for need in (1, 2):
+    tot = 0.0
+    for k in np.unique(cu_key):
+        m = cu_key == k
+        ev = sorted([(a, 1) for a in s_us[m]] + [(b, -1) for b in e_us[m]])
+        c, last, acc = 0, 0.0, 0.0
+        for tt, d in ev:
+            if c >= need:
+                acc += tt - last
+            c += d
+            last = tt
+        tot += acc
+    print("mean time a CU holds >= %d workgroup(s): %.1f us of %.1f" % (need, tot / len(np.unique(cu_key)), span))
