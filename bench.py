@@ -247,6 +247,8 @@ def main():
                     help="configs[4] shape: one step = a defended evaluation of --images images sharded over the ranks")
     ap.add_argument("--images", type=int, default=10000, help="--strong: images in the evaluated list")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
+    ap.add_argument("--retune", action="store_true",
+                    help="time the job lists on this box instead of installing the committed choice (profiles/r04_tuning_<arch>.txt)")
     ap.add_argument("--use_bn", action="store_true",
                     help="USE_BN: True variant of the generator (batch-statistics Batchnorm after every hidden layer, "
                          "tflib/ops/batchnorm.py:80-93); not a BASELINE config (the shipped cfgs have USE_BN: False)")
@@ -337,6 +339,19 @@ def main():
     # times the candidates and every other rank installs ITS choices (dg_export_tuning -> broadcast -> dg_import_tuning): all
     # ranks launch the same job lists, and the line below names them (tuning_id)
     shapes = [B] + ([(e0 - s0) % B] if args.strong and (e0 - s0) % B else [])      # + the ragged last batch of this rank's shard
+    # The committed choice of the profiling run (tools/collect_profiles.sh), when there is one for this architecture: the lists the
+    # rocprofv3 evidence under profiles/ was collected with -- so roofline.traffic can be quoted and two runs launch the same
+    # kernels.  A text for another configuration / CU count is refused by the engine (then, and with --retune, the lists are timed
+    # here); row counts it does not hold are timed as usual.  DG_TUNING_CACHE (gan.prepare) overrides.
+    committed = os.path.join(ROOT, "profiles", "r04_tuning_%s.txt" % ("mnist" if a.arch_id == 0 else "celeba"))
+    tuning_source = "timed in this process"
+    if not args.retune and not args.use_bn and not args.opt and "DG_TUNING_CACHE" not in os.environ and os.path.exists(committed):
+        try:
+            with open(committed) as fh:
+                if gan.import_tuning(fh.read()) > 0:
+                    tuning_source = "profiles/" + os.path.basename(committed)
+        except Exception:
+            pass
     if distributed and world > 1:
         if rank == 0:
             for b in shapes:
@@ -418,7 +433,7 @@ def main():
                        "parallelism": "shard%d" % world},
             "build": build_id(),
             # which job lists ran (a timed choice per layer and row count; identical ids = identical lists on every rank)
-            "tuning_id": tuning_id, "tuning_id_per_rank": rank_tuning,
+            "tuning_id": tuning_id, "tuning_id_per_rank": rank_tuning, "tuning_source": tuning_source,
             "ranks": dist.get_world_size() if distributed else 1,     # ranks the process group (RCCL) actually holds
             "ms_per_step_per_rank": [round(v, 3) for v in per_rank_ms],
             "roofline": roofline,
