@@ -56,8 +56,8 @@ def layer_labels(names, workload):
                 out.append(bwd[nb] if nb < len(bwd) else "B?"); nb += 1
         elif "tail" in k:
             seen_tail = True
-            out.append({"mnist_tail_pipe_kernel": "T5fb", "mnist_tail_mfma_kernel": "T5", "celeba_tail_fwd": "T6f", "celeba_tail_bwd": "T6b"}.get(
-                next((p for p in ("mnist_tail_pipe_kernel", "mnist_tail_mfma_kernel", "celeba_tail_fwd", "celeba_tail_bwd") if p in k), ""), "T?"))
+            out.append({"mnist_tail_pipe": "T5fb", "mnist_tail_mfma_kernel": "T5", "celeba_tail_fwd": "T6f", "celeba_tail_bwd": "T6b"}.get(
+                next((p for p in ("mnist_tail_pipe", "mnist_tail_mfma_kernel", "celeba_tail_fwd", "celeba_tail_bwd") if p in k), ""), "T?"))
         elif "momentum_update_kernel" in k:
             out.append("UPD")
             nf, nb, seen_tail = 0, 0, False
