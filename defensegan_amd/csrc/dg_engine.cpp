@@ -141,6 +141,8 @@ struct dg_handle {
     // shapes allow (any latent_dim that is a multiple of 32 up to 192 forward; latent_dim 128 and 256-wide K slices backward);
     // 0 = the position-batched kernel as for every other layer.  Bit-identical either way (same fma chains, same K slices).
     int latent_turn = 1;
+    int update_fold = 0;           // momentum update folded into the Linear backward launch (dg_linear.hip); needs latent_turn
+    unsigned* upd_count = nullptr; // one arrival counter per 32-row block (+ one per row group), zero between launches
     int lin_groups_fwd = 0, lin_groups_bwd = 0;   // workgroups per column tile / K slice; 0 = pick from the CU count
     int cu_count = 256;
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
@@ -410,6 +412,7 @@ void free_workspace(dg_handle* h) {
     for (auto& a : h->act) fr(a);
     for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
+    if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
     h->cap_rows = 0;
 }
 
@@ -421,6 +424,11 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     HIP_TRY(hipMalloc(&h->z, cap * h->latent * sizeof(float)));
     HIP_TRY(hipMalloc(&h->m, cap * h->latent * sizeof(float)));
     HIP_TRY(hipMalloc(&h->part, cap * h->nsplit * h->latent * sizeof(float)));
+    {
+        const size_t n_count = (size_t)(cap / 32 + 16);          // blocks + up to 8 row groups + slack
+        HIP_TRY(hipMalloc(&h->upd_count, n_count * sizeof(unsigned)));
+        HIP_TRY(hipMemset(h->upd_count, 0, n_count * sizeof(unsigned)));
+    }
     HIP_TRY(hipMalloc(&h->loss, cap * sizeof(float)));
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
     if (h->graph_max_rows > 0) {
@@ -714,9 +722,17 @@ int build_lin_packs(dg_handle* h) {
     return DG_OK;
 }
 
-int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+// The momentum update riding in the Linear backward launch: the rows' z / m, their arrival counters and the step's constants.
+struct UpdateFold {
+    float* z; float* m; unsigned* count; float lr, momentum;
+};
+
+int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof,
+                       const UpdateFold* uf = nullptr) {
     const bool fwd = &op == &h->F1;
     dg::LinArgs a;
+    a.upd_z = nullptr; a.upd_m = nullptr; a.upd_count = nullptr; a.upd_lr = 0.f; a.upd_momentum = 0.f;
+    if (uf && !fwd) { a.upd_z = uf->z; a.upd_m = uf->m; a.upd_count = uf->count; a.upd_lr = uf->lr; a.upd_momentum = uf->momentum; }
     a.A = A;
     a.Wp = fwd ? h->lin_pack_fwd : h->lin_pack_bwd;
     a.Out = Out;
@@ -744,7 +760,7 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
     a.trace = (h->d_job_trace && op.name == h->job_trace_op && a.units * a.groups * 2 <= kJobTraceCap) ? h->d_job_trace : nullptr;
 #endif
     char sym[64];
-    snprintf(sym, sizeof sym, "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
+    snprintf(sym, sizeof sym, a.upd_z ? "@lin_stationary_kernel<%d, %d, true>" : "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
     {
         ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
         dg::launch_lin_stationary(a, s);
@@ -966,7 +982,11 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     return DG_OK;
 }
 
-int run_backward(dg_handle* h, const RowGroup& g, bool prof) {
+bool update_folds(const dg_handle* h) {
+    return h->update_fold && h->upd_count && lin_stationary(h, h->B1) && dg::lin_fold_supported(h->nsplit, h->latent);
+}
+
+int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* uf = nullptr) {
     const int nd = (int)h->dec.size();
     const int64_t r0 = g.row0;
     for (int d = nd - 2; d >= 0; --d) {
@@ -981,6 +1001,7 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof) {
         ProfScope ps(h, g.s, prof, "BNb", 0.0);
         dg::launch_bn_backward(bn_args(h, h->ai[0], g.n_rows), g.s);
     }
+    if (uf) return run_lin_stationary(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof, uf);
     return run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
 
@@ -1017,10 +1038,17 @@ int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float mo
             int rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
             if (rc) return rc;
             if (last) continue;
+            const int64_t r0 = g.row0;
+            if (update_folds(h)) {
+                // row groups are whole images, not whole 32-row blocks: group gi's counters start at r0 / 32 + gi (disjoint)
+                const UpdateFold uf = {h->z + r0 * h->latent, h->m + r0 * h->latent, h->upd_count + r0 / 32 + gi, lr_k, momentum};
+                rc = run_backward(h, g, prof, &uf);
+                if (rc) return rc;
+                continue;
+            }
             rc = run_backward(h, g, prof);
             if (rc) return rc;
             ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
-            const int64_t r0 = g.row0;
             dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
                                        h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s);
         }
@@ -1364,6 +1392,9 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     if (z0) HIP_TRY(hipMemcpyAsync(h->z, z0, zbytes, hipMemcpyDeviceToDevice, s));
     else dg::launch_init_latents(h->z, n_rows, h->latent, seed, first_row, std::sqrt(1.0f / (float)h->latent), s);
     HIP_TRY(hipMemsetAsync(h->m, 0, zbytes, s));
+    // (the arrival counters of the folded update return to zero by themselves; cleared per call all the same, so that a call
+    // that died half-way cannot poison the next one)
+    if (update_folds(h)) HIP_TRY(hipMemsetAsync(h->upd_count, 0, (size_t)(n_rows / 32 + 16) * sizeof(unsigned), s));
     const int steps = L > 1 ? L : 1;
     // the batch split (by image) into row groups on separate streams (option two_streams)
     RowGroup grp[dg_handle::kMaxGroups];
@@ -1634,6 +1665,11 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         h->graph_broken = false;
         drop_graphs(h);
         free_workspace(h);               // the staging copy of the images is sized by this option
+        return DG_OK;
+    }
+    if (k == "update_fold") {            // 1 = the momentum update rides in the Linear backward launch (needs latent_turn)
+        HIP_TRY(hipDeviceSynchronize());
+        h->update_fold = atoi(value) != 0;
         return DG_OK;
     }
     if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel

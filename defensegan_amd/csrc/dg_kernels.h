@@ -94,12 +94,20 @@ struct LinArgs {
     int groups;              // workgroups per unit; group g owns the 32-row blocks g, g + groups, ...
     int kch;                 // 32-float K chunks per row: 2, 4 or 6 forward, 8 backward
     int mode;                // EpiMode (EPI_BIAS_RELU / EPI_BIAS forward, EPI_STORE backward)
+    // backward only, optional: the momentum update folded into this launch (dg_linear.hip, "folded update").  The workgroup
+    // that stores the LAST of a 32-row block's `units` K slices sums the slices in slice order and applies ApplyMomentum to
+    // upd_z / upd_m (both [n_rows][128], the rows of Out); upd_count = one arrival counter per 32-row block, zero between launches
+    float* upd_z;            // nullptr: partials only (momentum_update_kernel follows as its own launch)
+    float* upd_m;
+    unsigned* upd_count;
+    float upd_lr, upd_momentum;
 #ifdef DG_MEASURE
     long long* trace;        // optional [grid][8] shader-clock stamps of every workgroup: start, first block ready, first block
                              // multiplied, first block stored, end, HW_ID, blocks, -
 #endif
 };
 bool lin_stationary_supported(int kch, int mode);
+bool lin_fold_supported(int units, int latent);
 // float index inside Wp of element e of the fragment (unit, wave, chunk c, k-step kk, lane): the weight of output column
 // wave*32 + (lane & 31) of the unit at k = c*32 + (kk*2 + (lane >> 5))*4 + e
 __host__ __device__ inline long long lin_pack_index(int unit, int wave, int kch, int c, int kk, int lane, int e) {

@@ -21,6 +21,7 @@ namespace dg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DG_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -29,11 +30,15 @@ namespace {
 __device__ __forceinline__ int lswz(int row) { return (row >> 1) & 7; }
 
 // KCH: 32-float K chunks per block row (forward: latent / 32; backward: slice width / 32)
-template <int KCH, int MODE>
+// FOLD (backward only): the momentum update of a 32-row block rides in the workgroup that delivers the block's last K slice
+// ("folded update" below).
+template <int KCH, int MODE, bool FOLD = false>
 __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_stationary_kernel(LinArgs g) {
+    static_assert(!FOLD || MODE == EPI_STORE, "the folded update belongs to the split-K backward");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BLK_BYTES = KCH * 4096;             // one 32-row block: [KCH chunks][32 rows][128 B]
     char* const epi = smem + 2 * BLK_BYTES;           // [4 waves][32 x 32 floats] transposition tiles
+    unsigned* const sflag = reinterpret_cast<unsigned*>(epi + 4 * 4096);      // FOLD: "this workgroup was the last arriver", 2 slots
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,6 +97,14 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
 
     // block 0 and the weights are there; every wave's pieces of it too
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (FOLD) {
+        // (the weights ARE in their registers now; hipcc does not see the asm wait and, with this variant's single loop body,
+        // would otherwise wait for "outstanding" weight loads -- in fact for the next block's DMA -- after the first chunk of every block)
+#pragma unroll
+        for (int c = 0; c < KCH; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) asm volatile("" : "+v"(wf[c][kk]));
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // ---- write-out of a finished 32 x 32 tile, in three pieces that ride INSIDE the next block's MFMA stream (a wave that wrote
     // its tile out between two blocks left the matrix pipe idle for a fifth of a block, and two workgroups sharing a CU ran
@@ -118,7 +131,75 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
                 v[p][q] = t;
             }
             const int r = row0 + p * 8 + er;
-            if (r < g.n_rows) *reinterpret_cast<f32x4*>(g.Out + (long long)r * g.out_rowstride + ocol) = v[p];
+            if constexpr (FOLD) {
+                // write-through (sc1): another workgroup, on any XCD, sums these slices inside this launch
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    g.Out + (long long)row0 * g.out_rowstride, 0, 0x7ffffff0, 0x00020000);
+                if (r < g.n_rows)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[p]), orsrc,
+                                                           (int)((unsigned)(p * 8 + er) * (unsigned)(g.out_rowstride * 4) + (unsigned)ocol * 4u), 0, 16);
+            } else {
+                if (r < g.n_rows) *reinterpret_cast<f32x4*>(g.Out + (long long)r * g.out_rowstride + ocol) = v[p];
+            }
+        }
+    };
+
+    // ---- folded update (FOLD).  A 32-row block of dz is complete when all `units` K-slice workgroups of its row group have
+    // stored their partial tiles.  Every workgroup draws a ticket from the block's counter once ALL its waves' stores of that
+    // block have been acknowledged (write-through stores, s_waitcnt vmcnt(0) in every wave, barrier, one relaxed agent-scope
+    // fetch_add: the hand-off recipe of the programming guide, section 6 guideline 16 / split-K reduction); the workgroup that
+    // draws units - 1 reads all slices back with sc1 loads (L1 bypassed), adds them in SLICE ORDER from zero exactly as
+    // momentum_update_kernel does and applies m <- momentum * m + g, z <- z - lr * m (the same two fmas).
+    // The ticket is drawn one block late and read another block later, so its round trip never stalls the MFMA stream; only a
+    // workgroup's last two blocks are settled after its last multiply.  No workgroup ever waits for another one.
+    unsigned tk = 0;
+    auto arrive = [&](int blk) {
+        // (atomic inc with wrap at units - 1: the counter is back at zero after the last arrival.  Not fetch_add: hipcc rewrites
+        // an add in a divergent branch into a wave reduction that waits for the returned value on the spot)
+        if (tid == 0) tk = __builtin_amdgcn_atomic_inc32(g.upd_count + blk, (unsigned)(g.units - 1), __ATOMIC_RELAXED, "agent");
+    };
+    auto post_flag = [&](int slot) {                  // before a barrier: was the ticket drawn last time the block's last one?
+        if (tid == 0) sflag[slot & 1] = tk == (unsigned)(g.units - 1) ? 1u : 0u;
+    };
+    auto update_block = [&](int blk) {
+        const int row0 = blk << 5;
+        const int ur = tid >> 3, uq = (tid & 7) * 4;   // 8 lanes per row: one 128-B line per (slice, 32-column group)
+        const int r = row0 + ur;
+        if (r >= g.n_rows) return;
+        const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.Out + (long long)row0 * g.out_rowstride, 0, 0x7ffffff0, 0x00020000);
+        const unsigned rbase = (unsigned)ur * (unsigned)(g.out_rowstride * 4);
+#pragma unroll 1
+        for (int j = 0; j < 4; j += 2) {                     // two 32-column groups at a time: 16 loads in flight per lane
+            const int col = uq + 32 * j;
+            f32x4 sum0 = {0.f, 0.f, 0.f, 0.f}, sum1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int s0 = 0; s0 < g.units; s0 += 8) {        // units % 8 == 0 (launch_lin_stationary)
+                f32x4 pv[2][8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const unsigned off = rbase + (unsigned)((s0 + s) * g.out_unit + col) * 4u;
+                    pv[0][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, (int)off, 0, 16));
+                    pv[1][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, (int)off, 128, 16));
+                }
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { sum0 += pv[0][s]; sum1 += pv[1][s]; }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const f32x4 sum = jj ? sum1 : sum0;
+                float* mp = g.upd_m + (long long)r * 128 + col + 32 * jj;
+                float* zp = g.upd_z + (long long)r * 128 + col + 32 * jj;
+                f32x4 mv = *reinterpret_cast<const f32x4*>(mp);
+                f32x4 zv = *reinterpret_cast<const f32x4*>(zp);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    mv[q] = __builtin_fmaf(g.upd_momentum, mv[q], sum[q]);
+                    zv[q] = __builtin_fmaf(-g.upd_lr, mv[q], zv[q]);
+                }
+                *reinterpret_cast<f32x4*>(mp) = mv;
+                *reinterpret_cast<f32x4*>(zp) = zv;
+            }
         }
     };
 
@@ -161,7 +242,15 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
         if (tron && i == 0) tr[2] = (long long)__builtin_readcyclecounter();
         if (tron && i == 1) tr[3] = (long long)__builtin_readcyclecounter();
 #endif
-        if (i + 1 < n_my) {
+        if constexpr (FOLD) {
+            // block i-1's stores (issued seven chunks ago) and block i-2's ticket are back; after the barrier that holds for
+            // every wave: draw block i-1's ticket, settle block i-2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (i >= 2) post_flag(i);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (i >= 1) arrive(blk - g.groups);
+            if (i >= 2 && __builtin_amdgcn_readfirstlane((int)sflag[i & 1])) update_block(blk - 2 * g.groups);
+        } else if (i + 1 < n_my) {
             // this wave's pieces of block i+1 have landed once at most the 4 row stores of block i-1 (issued after them, inside
             // this block's stream; VMEM operations retire in order) are outstanding; then the barrier: every wave's pieces are
             // there, and every wave is done reading the buffer the block after that will be staged into
@@ -170,11 +259,22 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
+    const int last_blk = grp + (n_my - 1) * g.groups;
     {
         f32x4 v[4];
         out_write(done);
         out_read(v);
-        out_store(v, grp + (n_my - 1) * g.groups);
+        out_store(v, last_blk);
+    }
+    if constexpr (FOLD) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the last block's stores, the ticket of the one before
+        if (n_my >= 2) post_flag(n_my);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        arrive(last_blk);
+        if (n_my >= 2 && __builtin_amdgcn_readfirstlane((int)sflag[n_my & 1])) update_block(last_blk - g.groups);
+        post_flag(n_my + 1);                                             // (waits for the ticket just drawn)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (__builtin_amdgcn_readfirstlane((int)sflag[(n_my + 1) & 1])) update_block(last_blk);
     }
 #ifdef DG_MEASURE
     if (tron) {
@@ -187,20 +287,21 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
 #endif
 }
 
-template <int KCH, int MODE>
+template <int KCH, int MODE, bool FOLD = false>
 void launch_km(const LinArgs& a, hipStream_t s) {
-    const int lds = 2 * KCH * 4096 + 4 * 4096;
+    const int lds = 2 * KCH * 4096 + 4 * 4096 + (FOLD ? 16 : 0);
     static PerDeviceOnce attr;
     if (attr.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE, FOLD>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
 }
 
 template <int KCH>
 void launch_k(const LinArgs& a, hipStream_t s) {
     if constexpr (KCH == 8) {
-        launch_km<KCH, EPI_STORE>(a, s);                     // backward: split-K partials
+        if (a.upd_z) launch_km<KCH, EPI_STORE, true>(a, s);  // + the folded update (lin_fold_supported: the caller's check)
+        else launch_km<KCH, EPI_STORE>(a, s);                // backward: split-K partials
     } else {
         if (a.mode == EPI_BIAS) launch_km<KCH, EPI_BIAS>(a, s);      // forward with Batchnorm behind it
         else launch_km<KCH, EPI_BIAS_RELU>(a, s);
@@ -212,6 +313,9 @@ void launch_k(const LinArgs& a, hipStream_t s) {
 bool lin_stationary_supported(int kch, int mode) {
     return kch == 8 ? mode == EPI_STORE : ((kch == 2 || kch == 4 || kch == 6) && (mode == EPI_BIAS || mode == EPI_BIAS_RELU));
 }
+
+// the folded update reads the slices eight at a time and addresses z / m as [rows][128]
+bool lin_fold_supported(int units, int latent) { return units >= 8 && units % 8 == 0 && latent == 128; }
 
 void launch_lin_stationary(const LinArgs& a, hipStream_t s) {
     if (a.n_rows <= 0 || a.units <= 0 || a.groups <= 0) return;

@@ -84,10 +84,14 @@ BITWISE = {
               {"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01, "jobs.min_level": 0}, {"jobs.min_level": 1},
               {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300},
               # the latent turn: position-batched kernel instead of the weight-stationary ones; other workgroup counts
-              {"latent_turn": 0}, {"lin_groups_fwd": 3, "lin_groups_bwd": 5}, {"lin_groups_fwd": 64, "lin_groups_bwd": 64}],
+              {"latent_turn": 0}, {"lin_groups_fwd": 3, "lin_groups_bwd": 5}, {"lin_groups_fwd": 64, "lin_groups_bwd": 64},
+              # the momentum update folded into the Linear backward launch (last-arriving K slice), alone / with other group counts /
+              # with two row groups on two streams
+              {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 5}, {"update_fold": 1, "lin_groups_bwd": 64},
+              {"update_fold": 1, "two_streams": 2, "two_stream_min_rows": 64}],
     "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
                {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300},
-               {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}],
+               {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}, {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 3}],
 }
 
 
@@ -110,6 +114,29 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
         got = _run(g2, x, z0)
         for k in ("rec", "idx", "loss", "z"):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+@pytest.mark.parametrize("B,R,L", [(256, 10, 60), (121, 10, 40), (3, 1, 25)])
+def test_folded_update_is_bit_identical_over_many_steps(B, R, L):
+    """Option update_fold: the workgroup that delivers the last K slice of a 32-row block of dz applies the momentum update
+    inside the Linear backward launch (write-through partials, one arrival counter per block).  Every step reads the partials
+    other workgroups -- on other XCDs -- wrote into the SAME buffer a step earlier, so one stale word would change z for good:
+    after L steps z, the losses and the selection are bit-identical to the separate momentum_update_kernel's, twice in a row
+    (the counters are back at zero), at full (2560), ragged (1210) and tiny (3) row counts."""
+    a = archs.make_arch("mnist")
+    gan, p = _make("mnist", R=R, L=L)
+    rs = np.random.RandomState(17)
+    x = gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32))
+    x = np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32)
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=18)
+    z0 = synth.make_z(B * R, 128, seed=19)
+    ref = _run(gan, x, z0)
+    g2, _ = _make("mnist", R=R, L=L)
+    g2.set_option("update_fold", 1)
+    for rep in range(2):
+        got = _run(g2, x, z0)
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (rep, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
 
 
 @pytest.mark.parametrize("arch,latent_dim,net_dim", [("mnist", 128, 64), ("mnist", 64, 64), ("celeba", 192, 64), ("mnist", 128, 128)])
