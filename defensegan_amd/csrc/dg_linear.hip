@@ -15,6 +15,8 @@
 // inside a chunk the MFMA k-pairs (8kk + e, 8kk + 4 + e), e = 0..3, kk = 0..3) and the same epilogue expressions, so the
 // results are BIT-IDENTICAL to the generic kernel's (tests/test_gpu_variants.py) and, like them, independent of the batch a
 // row is in.  The backward keeps the engine's fixed K slices: slice sums are still added in slice order by the update.
+// Optional (engine option update_fold, off: measured slower, profiles/r04_ab_update_fold.txt): the update itself inside the backward
+// launch, done by the workgroup that delivers a row block's last slice ("folded update" below).
 #include "dg_kernels.h"
 
 namespace dg {

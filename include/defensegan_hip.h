@@ -173,6 +173,11 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "latent_turn"      1 (default): Linear backward / forward on the weight-stationary kernels (dg_linear.hip) where the shapes
  *                      allow; 0: on the position-batched kernel like every other layer.  "lin_groups_fwd" / "lin_groups_bwd":
  *                      their workgroups per column tile / K slice (0 = from the CU count)
+ *   "update_fold"      1: the momentum update rides in the Linear backward launch -- the workgroup that delivers the last K slice
+ *                      of a 32-row block sums the slices (write-through partials, one arrival counter per block) and applies the
+ *                      update; needs latent_turn, latent 128, nsplit a multiple of 8.  Bit-identical to the separate kernel and
+ *                      1.6 % SLOWER on the MNIST loop (the reducer of a row group becomes the last arriver of every later block of
+ *                      the group: profiles/r04_ab_update_fold.txt).  Default 0
  *   "graph_max_rows"   > 0: call shapes of at most this many latent rows replay a captured hipGraph of the L-step loop instead of
  *                      enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum); never while
  *                      the caller's stream is itself capturing).  Default 0 = always enqueue: measured no gain at the reference's
