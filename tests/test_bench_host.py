@@ -194,3 +194,45 @@ def test_self_launch_starts_one_rank_per_gpu(tmp_path):
     assert p.returncode == 0, p.stderr[-2000:]
     assert (tmp_path / "rank0").read_text() == "2 0 127.0.0.1 --gpus 2"
     assert (tmp_path / "rank1").read_text() == "2 1 127.0.0.1 --gpus 2"
+
+
+def test_kernel_trace_rows_are_labelled_with_the_bench_lines_layers(tmp_path):
+    """tools/kernel_trace_by_layer.py: launches grouped by (symbol, grid, LDS) and labelled with the layer of bench.py's
+    per-layer rows -- one symbol serving two layers is told apart by duration, the Linear kernels are matched although the trace
+    spells their defaulted template argument (`lin_stationary_kernel<4, 2, false>`), and the short update launch although the
+    hipEvent markers add several microseconds to its bench row."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    rows = [("void dg::gemm_batched_kernel<0, 3, 1>(dg::GemmArgs)", 2384 * 256, 49152, 311000),
+            ("void dg::gemm_batched_kernel<0, 3, 1>(dg::GemmArgs)", 1472 * 256, 49152, 279000),
+            ("void dg::(anonymous namespace)::lin_stationary_kernel<4, 2, false>(dg::LinArgs)", 512 * 256, 49152, 28000),
+            ("void dg::momentum_update_kernel(float*, float*, float const*, int, long long, int, float, float, float*)", 320 * 256, 0, 6100),
+            ("void dg::gemm_batched_kernel<0, 3, 1>(dg::GemmArgs)", 999 * 256, 49152, 300000)]          # a candidate list: 3 launches only
+    trace = tmp_path / "kernel_trace.csv"
+    with open(trace, "w") as fh:
+        fh.write("Kernel_Name,Grid_Size_X,Workgroup_Size_X,LDS_Block_Size,Start_Timestamp,End_Timestamp\n")
+        t = 0
+        for rep in range(70):
+            for i, (name, grid, lds, ns) in enumerate(rows):
+                if i == 4 and rep >= 3:
+                    continue
+                fh.write('"%s",%d,256,%d,%d,%d\n' % (name, grid, lds, t, t + ns + rep % 3))
+                t += ns + 5000
+    line = {"kernels": [{"name": "B3", "kernel": "gemm_batched_kernel<0, 3, 1>", "avg_us": 314.0},
+                        {"name": "B2", "kernel": "gemm_batched_kernel<0, 3, 1>", "avg_us": 282.0},
+                        {"name": "F1", "kernel": "lin_stationary_kernel<4, 2>", "avg_us": 33.5},
+                        {"name": "UPD", "kernel": "momentum_update_kernel", "avg_us": 11.5}]}
+    bj = tmp_path / "bench.json"
+    bj.write_text(json.dumps(line) + "\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_trace_by_layer.py"), str(trace), str(bj)],
+                         capture_output=True, text=True, check=True).stdout.splitlines()
+    got = {}
+    import csv
+    for r in csv.DictReader(out):
+        got[(r["Layer"], r["Kernel"])] = (int(r["Calls"]), float(r["AverageNs"]))
+    assert got[("B3", "gemm_batched_kernel<0, 3, 1>")][0] == 70 and abs(got[("B3", "gemm_batched_kernel<0, 3, 1>")][1] - 311001) < 2
+    assert got[("B2", "gemm_batched_kernel<0, 3, 1>")][0] == 70
+    assert got[("F1", "lin_stationary_kernel<4, 2, false>")][0] == 70
+    assert got[("UPD", "momentum_update_kernel")][0] == 70
+    assert got[("", "gemm_batched_kernel<0, 3, 1> [candidate job lists, not kept]")][0] == 3
