@@ -369,3 +369,44 @@ def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
     assert (touched == 1).all() and np.allclose(out, ref, rtol=1e-12, atol=1e-12)
     lib.dgp2_free(b)
     lib.dgp_free(h)
+
+
+def test_committed_tuning_files_describe_lists_this_planner_builds(lib):
+    """profiles/r04_tuning_{mnist,celeba}.txt are what bench.py installs by default (dg_import_tuning) so that its launches are the
+    ones the committed rocprofv3 / PMC evidence was collected on.  The engine refuses a record whose job count this build's
+    planner does not reproduce (bench.py then times afresh and `roofline.traffic` goes null): a change to dg_plan.cpp that
+    orphans the committed files must show up here, on the CPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    layers = {       # the engine's build_plans() for NET_DIM 64 without Batchnorm: (kind, h_in, in_pitch, e_out, out_pitch, cin, cout, bn)
+        "mnist": {"F2": ("deconv_fwd", 4, 4, 7, 7, 256, 128, 128), "F3": ("deconv_fwd", 7, 7, 14, 14, 128, 64, 64),
+                  "B2": ("deconv_bwd", 4, 4, 7, 7, 256, 128, 256), "B3": ("deconv_bwd", 7, 7, 14, 14, 128, 64, 128)},
+        "celeba": {"F2": ("deconv_fwd", 4, 4, 8, 8, 256, 128, 128), "F3": ("deconv_fwd", 8, 8, 16, 16, 128, 64, 64),
+                   "F5": ("deconv_fwd", 16, 16, 32, 32, 64, 64, 64), "B2": ("deconv_bwd", 4, 4, 8, 8, 256, 128, 256),
+                   "B3": ("deconv_bwd", 8, 8, 16, 16, 128, 64, 128), "B5": ("deconv_bwd", 16, 16, 32, 32, 64, 64, 64)},
+    }
+    slots = {0: 2, 1: 3, 2: 5}                       # dg_handle::job_slots_per_cu
+    checked = 0
+    for wl, table in layers.items():
+        path = os.path.join(root, "profiles", "r04_tuning_%s.txt" % wl)
+        if not os.path.exists(path):
+            continue
+        lines = open(path).read().splitlines()
+        head = lines[0].split()
+        assert head[:2] == ["dgtune", "1"] and head[head.index("net_dim") + 1] == "64" and head[head.index("use_bn") + 1] == "0"
+        cus = int(head[head.index("cus") + 1])
+        seen = set()
+        for line in lines[1:]:
+            f = line.split()
+            if f[0] not in table:
+                continue                              # Linear layers: on the weight-stationary kernels, no job list in use
+            h, _ = build(lib, *table[f[0]])
+            b = lib.dgp2_build(h)
+            rc = lib.dgp2_rebuild_matches(b, (line + "\n").encode(), 0, cus, slots[int(f[2])])
+            assert rc >= 0, (wl, line, rc)            # -2: the planner makes another number of jobs, -1: malformed
+            lib.dgp2_free(b)
+            lib.dgp_free(h)
+            seen.add(f[0])
+            checked += 1
+        assert seen == set(table), (wl, seen)
+    if not checked:
+        pytest.skip("no committed tuning files")
