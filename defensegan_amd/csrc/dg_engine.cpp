@@ -608,8 +608,22 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             *ms_out = ms / reps;
             return true;
         };
+        // Two stages (the tapered lists doubled the candidates, and every first use of a call shape -- the ragged last batch of
+        // an evaluation included -- pays for them): the plain lists of every starting level first; tapered lists are then timed
+        // only for the levels whose best plain list came within 2 % of the best overall (a taper re-cuts the END of a list, it
+        // does not make up for a starting level that is 5-10 % behind).
+        float level_best[3] = {1e30f, 1e30f, 1e30f};
         for (size_t i = 0; ok && i < cands.size(); ++i) {
             Cand& c = cands[i];
+            if (c.jl.taper > 0.0) continue;
+            ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+            if (ok && c.ms < level_best[c.jl.min_level]) level_best[c.jl.min_level] = c.ms;
+        }
+        const float plain_best = std::min(level_best[0], std::min(level_best[1], level_best[2]));
+        for (size_t i = 0; ok && i < cands.size(); ++i) {
+            Cand& c = cands[i];
+            if (c.jl.taper <= 0.0) continue;
+            if (level_best[c.jl.min_level] > 1.02f * plain_best) { c.ms = 1e30f; continue; }      // never uploaded, never kept
             ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
         }
         if (ok) {
@@ -649,6 +663,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             cands[best].jl.measured_us = cands[best].ms * 1e3;
             if (getenv("DG_TUNE_VERBOSE")) {
                 for (size_t i = 0; i < cands.size(); ++i)
+                    if (cands[i].ms < 1e29f)
                     fprintf(stderr, "[dg tune] %s rows %d level %d%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
                             n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake ? " snake" : "      ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
@@ -917,8 +932,9 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
         t.do_backward = tail_backward ? 1 : 0;
         t.pipe = h->tail_pipe;
         t.want_loss = want_loss ? 1 : 0;
-        // the third-generation kernel leaves the per-row loss alone: a launch whose loss is read (dg_loss_grad) runs the first
-        t.pipe_version = (h->tail_pipe_version == 3 && want_loss) ? 1 : h->tail_pipe_version;
+        // the third-generation kernel writes neither the per-row loss nor y: a launch whose loss or image is read (dg_loss_grad
+        // with out_loss and / or out_y) runs the first
+        t.pipe_version = (h->tail_pipe_version == 3 && (want_loss || want_y)) ? 1 : h->tail_pipe_version;
 #ifdef DG_MEASURE
         t.dbg = h->tail_dbg;
         t.trace = h->d_tail_trace;
@@ -1576,13 +1592,13 @@ int dg_import_tuning(dg_handle* h, const char* text) {
             return fail(DG_E_INVALID, "layer %s, %d rows: the record describes %d jobs, this build makes %d (other cost model or planner)",
                         r.op.c_str(), r.n_rows, r.n_jobs, (int)jobs.size());
         if (!upload_jobs(jl, jobs)) return fail(DG_E_NOMEM, "cannot upload the job list of layer %s", r.op.c_str());
+        ++h->list_epoch;                 // from here on lists are replaced: a captured loop may point at one (also when a later record fails)
         for (auto it = op->jobs.begin(); it != op->jobs.end();)
             if (it->n_rows == r.n_rows) { (void)hipFree(it->d_jobs); it = op->jobs.erase(it); } else ++it;
         if (op->jobs.size() >= 16) { (void)hipFree(op->jobs.front().d_jobs); op->jobs.erase(op->jobs.begin()); }
         op->jobs.push_back(jl);
         ++n_imported;
     }
-    ++h->list_epoch;
     return n_imported;
 }
 
@@ -1639,10 +1655,17 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     return cnt;
 }
 
+static int set_option(dg_handle* h, const char* key, const char* value);
+
 int dg_set_option(dg_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
+    const int rc = set_option(h, key, value);
+    if (rc == DG_OK) ++h->list_epoch;    // an accepted option: captured loops are rebuilt on their next use (a refused one changes nothing)
+    return rc;
+}
+
+static int set_option(dg_handle* h, const char* key, const char* value) {
     const std::string k(key);
-    ++h->list_epoch;                     // whatever changes, captured loops are rebuilt on their next use
     if (k == "two_streams") {
         h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
@@ -1668,6 +1691,7 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "update_fold") {            // 1 = the momentum update rides in the Linear backward launch (needs latent_turn)
+        HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         h->update_fold = atoi(value) != 0;
         return DG_OK;

@@ -502,9 +502,21 @@ class DefenseGANBase(object):
 
 
 def tuning_text_id(text: str) -> str:
+    """12 hex digits naming the job lists a dg_export_tuning text describes.  A record is
+    ``op n_rows min_level slack snake xcd_order xcd_head n_jobs measured_us [taper]`` (dg_plan.cpp format_tune_record):
+    every field but ``measured_us`` (index 8, informational: two timings of the same list differ) enters the id, the taper
+    -- which does change the list -- included; a 9-field record of an older text is a taper of 0."""
     import hashlib
-    lines = [ln.rsplit(" ", 1)[0] if i else ln for i, ln in enumerate(text.strip().splitlines())]     # drop measured_us
-    return hashlib.sha256("\n".join(sorted(lines[1:]) if len(lines) > 1 else lines).encode()).hexdigest()[:12]
+    lines = text.strip().splitlines()
+    keys = []
+    for ln in lines[1:]:
+        f = ln.split()
+        if len(f) < 9:
+            keys.append(" ".join(f))         # not a record this build writes: hashed as it is
+            continue
+        taper = f[9] if len(f) > 9 else "0"
+        keys.append(" ".join(f[:8] + ["%.17g" % float(taper)]))
+    return hashlib.sha256("\n".join(sorted(keys) if keys else lines).encode()).hexdigest()[:12]
 
 
 class ReconstructionLayer(object):

@@ -288,3 +288,34 @@ def test_divergent_runs_return_and_never_select_a_nan(arch):
     gan.rec_lr = 10.0
     ok = gan.reconstruct(x, z_init_val=z0, return_details=True)    # the handle is still usable afterwards
     assert np.isfinite(ok["loss"]).all()
+
+
+def test_loss_grad_optional_outputs_through_the_c_abi():
+    """include/defensegan_hip.h lets out_y / out_loss / out_dz of dg_loss_grad be NULL independently.  At >= 512 rows the MNIST
+    tail would run the third-generation pipelined kernel, which writes neither the per-row loss nor y: a call that asks for y (or
+    the loss) must fall back to the kernel that does -- every combination returns what the all-outputs call returns."""
+    import ctypes as C
+    import torch
+    B, R = 60, 10                                   # 600 rows: above the pipelined tail's threshold (2 x 256)
+    gan, p = _make("mnist", R=R, L=3)
+    a = archs.make_arch("mnist")
+    rs = np.random.RandomState(3)
+    x = gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32))
+    x = torch.as_tensor(synth.adversarial(np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32), 0.3, a.in_lo, a.in_hi, seed=4)).cuda()
+    z = torch.as_tensor(synth.make_z(B * R, 128, seed=5)).cuda()
+    y_ref, loss_ref, dz_ref = gan.loss_grad(x, z)
+    lib, h = gan._lib(), gan._handle
+    stream = torch.cuda.current_stream().cuda_stream
+    for want_y, want_loss, want_dz in [(1, 0, 1), (1, 0, 0), (0, 1, 1), (0, 0, 1), (1, 1, 0), (0, 1, 0)]:
+        y = torch.full_like(y_ref, float("nan"))
+        loss = torch.full_like(loss_ref, float("nan"))
+        dz = torch.full_like(dz_ref, float("nan"))
+        gan._check(lib.dg_loss_grad(h, x.data_ptr(), z.data_ptr(), B, R, y.data_ptr() if want_y else None,
+                                    loss.data_ptr() if want_loss else None, dz.data_ptr() if want_dz else None, stream))
+        torch.cuda.synchronize()
+        if want_y:
+            assert torch.equal(y, y_ref), (want_y, want_loss, want_dz)
+        if want_loss:
+            assert torch.equal(loss, loss_ref), (want_y, want_loss, want_dz)
+        if want_dz:
+            assert torch.equal(dz, dz_ref), (want_y, want_loss, want_dz)

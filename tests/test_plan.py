@@ -341,6 +341,13 @@ def test_tuning_text_id_ignores_order_and_measured_durations():
     b = head + "B2 2560 1 1 0 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
     c = head + "B2 2560 1 1 1 0 0 1344 281.000\nF2 2560 1 0.97 0 0 0 2024 299.500\n"
     assert tuning_text_id(a) == tuning_text_id(b) != tuning_text_id(c)
+    # the records this build writes have a tenth field, the taper (it changes the list; measured_us, the ninth, does not)
+    a10 = head + "F2 2560 1 1e+30 0 0 0 2384 266.517 0.65000000000000002\nB2 2560 0 1 0 0 0 1472 275.302 0.5\n"
+    b10 = head + "B2 2560 0 1 0 0 0 1472 279.000 0.5\nF2 2560 1 1e+30 0 0 0 2384 270.100 0.65000000000000002\n"
+    c10 = head + "B2 2560 0 1 0 0 0 1472 275.302 0.65\nF2 2560 1 1e+30 0 0 0 2384 266.517 0.65000000000000002\n"
+    assert tuning_text_id(a10) == tuning_text_id(b10) != tuning_text_id(c10)
+    # a nine-field record of a round-4a text is a taper of 0
+    assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 293.500\n") == tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0\n")
 
 
 def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
