@@ -84,6 +84,7 @@ def traffic_for(workload, layers, B, R, tuning_id=None):
 
 
 TRAFFIC_FILE = "r04_pmc_traffic.json"
+TUNING_FILE = "r04_tuning_%s.txt"       # profiles/: the job-list choice of the profiling run, per architecture
 
 
 def make_inputs(gan, a, B, rank=0, first_image=0):
@@ -110,25 +111,55 @@ def _cpu_model():
     return "unknown"
 
 
+def physical_cores_one_socket():
+    """(physical cores of socket 0, logical CPUs) from /proc/cpuinfo; (None, n) when it cannot be read."""
+    ncpu = os.cpu_count() or 1
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k == "physical id":
+                    phys = v.strip()
+                elif k == "core id":
+                    core = v.strip()
+                elif not k and phys is not None and core is not None:
+                    if phys == "0":
+                        cores.add(core)
+                    phys = core = None
+        if phys == "0" and core is not None:
+            cores.add(core)
+        return (len(cores) or None), ncpu
+    except OSError:
+        return None, ncpu
+
+
 def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
     """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed here) on this box's host
-    cores.  The thread count is probed on 2-step runs (oversubscribing these small convolutions is slower than using fewer
-    threads); then ONE batch of 16 images runs the FULL L steps at the best thread count -- a measured number, not a short
-    sample scaled by (2L-1) -- unless the probe predicts more than `budget_s` seconds, in which case the batch shrinks to 8 / 4
-    images before the step count does (and the sample line says what was done)."""
+    cores.  Thread count: the best of {8, 16, 32, 64, physical cores of one socket} on 2-step probes, each probe the FASTEST of
+    three repeats (round 4 probed once per count and saw 2.6 ... 5.3 images/s for the same batch on three boxes of one CPU
+    model: a single noisy probe picked the count).  Then TWO batches of 16 images run the FULL L steps at that count -- measured,
+    not a short sample scaled by (2L-1) -- `value` is the faster one, `spread` = (slower - faster) / faster, both times are in
+    `sample`; if the probe predicts more than `budget_s` seconds per batch it shrinks to 8 / 4 images before the step count does."""
     from oracle import torch_ref as T          # checker / baseline only -- never on the product path
-    ncpu = os.cpu_count() or 1
+    phys, ncpu = physical_cores_one_socket()
     gen = T.TorchGenerator(params, arch)
     a = archs.make_arch(arch)
     nimg = min(16, len(x_np))
     z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
     best = None
-    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, phys or 64)}):
         torch.set_num_threads(th)
         T.reconstruct(params, x_np[:nimg], z0, R, 1, arch=arch, gen=gen)      # warm-up
-        t0 = time.perf_counter()
-        T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
-        probe = time.perf_counter() - t0
+        probe = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
+            dtp = time.perf_counter() - t0
+            probe = dtp if probe is None else min(probe, dtp)
+            if dtp > 10:
+                break
         if best is None or probe < best[0]:
             best = (probe, th)
         if probe > 20:
@@ -141,13 +172,17 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
         n_run //= 2
     if per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
         Ls = int(max(3, (budget_s / (per_pass * n_run / float(nimg)) + 1) // 2))
-    t0 = time.perf_counter()
-    T.reconstruct(params, x_np[:n_run], z0[:n_run * R], R, Ls, arch=arch, gen=gen)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        T.reconstruct(params, x_np[:n_run], z0[:n_run * R], R, Ls, arch=arch, gen=gen)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # == dt when the full L ran
-    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads of %d host cores, %.1f s measured%s" % (
-        n_run, R, Ls, threads, ncpu, dt, "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
+    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads (best of 2-step probes, 3 repeats each) of %d host CPUs (%s physical cores on socket 0), two batches %.1f s and %.1f s, the faster one reported%s" % (
+        n_run, R, Ls, threads, ncpu, phys if phys else "?", times[0], times[1], "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
     return {"value": n_run / t_full, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": ncpu,
+            "physical_cores_socket0": phys, "spread": round((max(times) - dt) / dt, 4),
             "cpu_model": _cpu_model(), "kind": "port", "sample": sample}
 
 
@@ -168,7 +203,14 @@ def roofline_from_profile(prof, workload, B, R, path_tflops, tuning_id=None):
         g["ms"] += p["ms"]; g["flops"] += p["flops"]; g["launches"] += p["launches"]
     dom = None
     if groups:
-        sym = max(groups, key=lambda k: groups[k]["ms"])          # dominant kernel = most total time
+        # dominant kernel symbol = the one that did the most ALGORITHMIC FLOP in the profiled step; ties -> the symbol launched
+        # first in a GD iteration (the forward layer).  (Round 4 took the symbol with the most TIME: Generator.3's forward and
+        # backward run as two symbols with the same FLOP and durations 0.05 % apart, so the choice flipped from run to run.)
+        order = []
+        for k in kernels:
+            if k["kernel"] not in order:
+                order.append(k["kernel"])
+        sym = max(order, key=lambda q: (round(groups[q]["flops"] / max(g_["flops"] for g_ in groups.values()), 3), -order.index(q)))
         g = groups[sym]
         dom = {"kernel": sym, "avg_us": round(g["ms"] / g["launches"] * 1e3, 2),
                "flop_per_launch": g["flops"] / g["launches"],
@@ -188,6 +230,10 @@ def roofline_from_profile(prof, workload, B, R, path_tflops, tuning_id=None):
         "path_achieved": round(path_tflops, 2),
         "path_frac": round(path_tflops / PEAK_FP32_TFLOPS, 4),
         "sum_kernel_ms_per_step": round(sum(g["ms"] for g in groups.values()), 3) if groups else None,
+        # every MFMA layer of the loop, largest first: the roofline fraction does not hang on which one is called dominant
+        "mfma_layers": [{"layer": k["name"], "kernel": k["kernel"], "avg_us": k["avg_us"], "tflops": k["tflops"],
+                         "frac": round(k["tflops"] / PEAK_FP32_TFLOPS, 4)}
+                        for k in sorted(kernels, key=lambda q: -q["tflops"] * q["avg_us"]) if k["tflops"] > 0][:8],
     }
     return kernels, roofline
 
@@ -198,6 +244,28 @@ def self_launch_command(argv, n_gpus, port):
     hostname may not resolve).  `argv` = the bench's own arguments, passed through unchanged."""
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
             "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def rank_cpus(local_rank, local_world, cpus):
+    """The host CPUs rank `local_rank` of `local_world` ranks on this node enqueues from: a contiguous 1 / local_world slice of
+    the CPUs this process may run on (sorted), at most 8 of them -- a rank's ~1600 enqueues per projection call then stay on
+    the cores (and the NUMA node) they started on instead of migrating between calls."""
+    cpus = sorted(cpus)
+    per = max(1, len(cpus) // max(1, local_world))
+    mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+    return mine[:8]
+
+
+def pin_host_thread(local_rank, local_world):
+    """os.sched_setaffinity by LOCAL_RANK (DG_BENCH_PIN=0 switches it off); returns the CPU list, or None when not pinned."""
+    if os.environ.get("DG_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        mine = rank_cpus(local_rank, local_world, os.sched_getaffinity(0))
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
 
 
 def _free_port():
@@ -264,6 +332,7 @@ def main():
         raise SystemExit(subprocess.call(self_launch_command(sys.argv[1:], args.gpus, _free_port()), env=env))
     # DG_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (used to test it on a 1-GPU box)
     distributed = world > 1 or os.environ.get("DG_BENCH_FORCE_DIST") == "1"
+    pinned = pin_host_thread(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -297,75 +366,98 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    st = {}                       # what the setup below leaves for the timed loop: x, step(i), labels / classifier (--strong)
     if args.strong:
-        # ---- configs[4]: a fixed image list, sharded by image; ONE gather of (labels, preds, diffs) per evaluation
         from defensegan_amd import gan_defense, network_builder as nb
         n_total = args.images
         s0, e0 = gan_defense.shard_range(n_total, rank, world)
-        clf = nb.model_a()
-        clf._device = local_rank
-        clf.init_like_reference(seed=5)
-        # untimed setup, the step BEFORE the path (whitebox.py:198-210): clean images G(z_true) keyed by the global image
-        # index, labels = the classifier's predictions on them, x = FastGradientMethod(classifier).generate(eps = 0.3,
-        # clip [0, 1]) on the bare classifier (the attack is built before the reconstruction layer is attached)
-        fgsm = nb.FastGradientMethod(clf)
-        xs, ls = [], []
-        for i in range(s0, e0, 2000):
-            n_i = min(2000, e0 - i)
-            clean = gan.generate(gan.init_latents(n_i, seed=1000, first_row=i))
-            lab = clf.fprop(clean)["logits"].argmax(dim=1)
-            xs.append(fgsm.generate(clean, eps=0.3, y=lab, clip_min=a.in_lo, clip_max=a.in_hi))
-            ls.append(lab.cpu().numpy())
-        x = torch.cat(xs).contiguous() if xs else torch.empty((0,) + tuple(a.image_dim), device=dev)
-        labels = np.concatenate(ls) if ls else np.zeros(0, np.int64)
-        result = {}
-
-        def step(i):
-            acc, roc = gan_defense.model_eval_gan_sharded(gan.reconstruct, clf, x, labels, batch_size=B, rec_rr=R,
-                                                          n_total=n_total, seed=2024 + i)
-            result["acc"], result["roc"] = acc, roc
-            return None
+        # model_eval_gan coalesces the caller's batches of B images into engine calls of up to COALESCE_ROWS latent rows
+        # (--batch 50 = the reference's BATCH_SIZE: 25 caller batches per call): the shapes the engine has to be prepared for,
+        # + the ragged last call of this rank's shard
+        B_call = gan_defense.engine_batch_images(B, R, max(e0 - s0, 1))
+        shapes = [B_call] + ([(e0 - s0) % B_call] if (e0 - s0) % B_call else [])
         units_per_step = n_total
     else:
-        x = make_inputs(gan, a, B, rank)
-
-        def step(i):
-            # a new batch of images every step: global row index advances, so z0 differs
-            first_row = ((i * world) + rank) * B * R
-            return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
+        shapes = [B]
         units_per_step = world * B
+    result = {}
+
+    def build_inputs():
+        if args.strong:
+            # ---- configs[4]: a fixed image list, sharded by image; ONE gather of (labels, preds, diffs) per evaluation
+            clf = nb.model_a()
+            clf._device = local_rank
+            clf.init_like_reference(seed=5)
+            # untimed setup, the step BEFORE the path (whitebox.py:198-210): clean images G(z_true) keyed by the global image
+            # index, labels = the classifier's predictions on them, x = FastGradientMethod(classifier).generate(eps = 0.3,
+            # clip [0, 1]) on the bare classifier (the attack is built before the reconstruction layer is attached)
+            fgsm = nb.FastGradientMethod(clf)
+            xs, ls = [], []
+            for i in range(s0, e0, 2000):
+                n_i = min(2000, e0 - i)
+                clean = gan.generate(gan.init_latents(n_i, seed=1000, first_row=i))
+                lab = clf.fprop(clean)["logits"].argmax(dim=1)
+                xs.append(fgsm.generate(clean, eps=0.3, y=lab, clip_min=a.in_lo, clip_max=a.in_hi))
+                ls.append(lab.cpu().numpy())
+            x = torch.cat(xs).contiguous() if xs else torch.empty((0,) + tuple(a.image_dim), device=dev)
+            labels = np.concatenate(ls) if ls else np.zeros(0, np.int64)
+
+            def step(i):
+                acc, roc = gan_defense.model_eval_gan_sharded(gan.reconstruct, clf, x, labels, batch_size=B, rec_rr=R,
+                                                              n_total=n_total, seed=2024 + i)
+                result["acc"], result["roc"] = acc, roc
+                return None
+        else:
+            x = make_inputs(gan, a, B, rank)
+
+            def step(i):
+                # a new batch of images every step: global row index advances, so z0 differs
+                first_row = ((i * world) + rank) * B * R
+                return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
+        st["x"], st["step"] = x, step
 
     # workspace + timed job lists: outside the hot call (dg_prepare); the steps below only enqueue.  With several ranks, rank 0
     # times the candidates and every other rank installs ITS choices (dg_export_tuning -> broadcast -> dg_import_tuning): all
-    # ranks launch the same job lists, and the line below names them (tuning_id)
-    shapes = [B] + ([(e0 - s0) % B] if args.strong and (e0 - s0) % B else [])      # + the ragged last batch of this rank's shard
+    # ranks launch the same job lists, and the line below names them (tuning_id).
     # The committed choice of the profiling run (tools/collect_profiles.sh), when there is one for this architecture: the lists the
     # rocprofv3 evidence under profiles/ was collected with -- so roofline.traffic can be quoted and two runs launch the same
     # kernels.  A text for another configuration / CU count is refused by the engine (then, and with --retune, the lists are timed
     # here); row counts it does not hold are timed as usual.  DG_TUNING_CACHE (gan.prepare) overrides.
-    committed = os.path.join(ROOT, "profiles", "r04_tuning_%s.txt" % ("mnist" if a.arch_id == 0 else "celeba"))
-    tuning_source = "timed in this process"
-    if not args.retune and not args.use_bn and not args.opt and "DG_TUNING_CACHE" not in os.environ and os.path.exists(committed):
-        try:
-            with open(committed) as fh:
-                if gan.import_tuning(fh.read()) > 0:
-                    tuning_source = "profiles/" + os.path.basename(committed)
-        except Exception:
-            pass
-    if distributed and world > 1:
-        if rank == 0:
-            for b in shapes:
-                gan.prepare(b)
-            payload = torch.tensor(list(gan.export_tuning().encode()), dtype=torch.uint8, device=dev)
-            n_bytes = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
-        else:
-            n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(n_bytes, 0)
-        if rank != 0:
-            payload = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(payload, 0)
-        if rank != 0:
-            gan.import_tuning(bytes(payload.cpu().tolist()).decode())
+    committed = os.path.join(ROOT, "profiles", TUNING_FILE % ("mnist" if a.arch_id == 0 else "celeba"))
+    tun = {"source": "timed in this process"}
+
+    def install_job_lists():
+        if not args.retune and not args.use_bn and not args.opt and "DG_TUNING_CACHE" not in os.environ and os.path.exists(committed):
+            try:
+                with open(committed) as fh:
+                    if gan.import_tuning(fh.read()) > 0:
+                        tun["source"] = "profiles/" + os.path.basename(committed)
+            except Exception as e:         # another configuration / CU count / planner: said in the JSON line, then timed here
+                tun["source"] = "timed in this process (profiles/%s refused: %s)" % (os.path.basename(committed), str(e)[:200])
+        if distributed and world > 1:
+            if rank == 0:
+                for b in shapes:
+                    gan.prepare(b)
+                payload = torch.tensor(list(gan.export_tuning().encode()), dtype=torch.uint8, device=dev)
+                n_bytes = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+            else:
+                n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
+            dist.broadcast(n_bytes, 0)
+            if rank != 0:
+                payload = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
+            dist.broadcast(payload, 0)
+            if rank != 0:
+                gan.import_tuning(bytes(payload.cpu().tolist()).decode())
+
+    # rank 0 times / installs its lists and sends them off FIRST and builds its inputs afterwards; the other ranks build their
+    # inputs first and pick the lists up when they are done: rank 0's dg_prepare overlaps their setup instead of following it
+    if rank == 0:
+        install_job_lists()
+        build_inputs()
+    else:
+        build_inputs()
+        install_job_lists()
+    x, step, tuning_source = st["x"], st["step"], tun["source"]
     for b in shapes:
         gan.prepare(b)
     tuning_id = gan.tuning_id()
@@ -407,6 +499,19 @@ def main():
         profiled_step_ms = (time.perf_counter() - tp0) * 1e3
         gan.profile_enable(0)
         prof = gan.profile_read()
+    # every rank's duration of the layer with the most FLOP in that marked step: the same job list does the same number of
+    # matrix-pipe cycles on every rank, so the ratio of these durations is the ratio of the GEMM clocks the ranks sustained
+    # (the per-rank "GEMM clock" a PMC pass would give as GRBM cycles / duration; counters cannot be read from inside the bench)
+    big_layer_us = [None]
+    if prof:
+        top = max((p_ for p_ in prof if p_["launches"]), key=lambda p_: p_["flops"] / p_["launches"], default=None)
+        if top:
+            big_layer_us = [round(top["ms"] / top["launches"] * 1e3, 2)]
+            if distributed:
+                mine = torch.tensor([big_layer_us[0]], dtype=torch.float64, device=dev)
+                allr = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(allr, mine)
+                big_layer_us = [round(float(t.item()), 2) for t in allr]
 
     if rank == 0:
         value = units_per_step * args.steps / dt
@@ -436,6 +541,8 @@ def main():
             "tuning_id": tuning_id, "tuning_id_per_rank": rank_tuning, "tuning_source": tuning_source,
             "ranks": dist.get_world_size() if distributed else 1,     # ranks the process group (RCCL) actually holds
             "ms_per_step_per_rank": [round(v, 3) for v in per_rank_ms],
+            "biggest_layer_us_per_rank": big_layer_us,     # duration ratio between ranks = ratio of their GEMM clocks
+            "host_cpus_rank0": pinned,        # the CPUs rank 0's host thread is pinned to (multi-rank runs; None = not pinned)
             "roofline": roofline,
             "kernels": kernels,
         }

@@ -65,6 +65,19 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         q = (int)__umulhi(jj << 1, magic);             // jj / s, magic = ceil(2^31 / s): exact for jj < 2^20, branch-free for s = 1
         j = (int)jj - q * s_cnt;
     };
+    // position j of the class -> float offsets inside an A row / an output row.  A class with taps is a rectangular grid
+    // (dg_types.h ClassDesc): computed from the job record -- no table fetch between the job record and the first operand DMA
+    const bool grid = jb.wc != 0;
+    auto pos_of_a = [&](int j) -> int {
+        if (!grid) return g.pos_a[jb.pos_begin + j];
+        const int jh = (int)__umulhi((unsigned)j << 1, jb.wc_magic);
+        return jb.a_base + jh * jb.a_rs + (j - jh * jb.wc) * jb.a_cs;
+    };
+    auto pos_of_out = [&](int j) -> int {
+        if (!grid) return g.pos_out[jb.pos_begin + j];
+        const int jh = (int)__umulhi((unsigned)j << 1, jb.wc_magic);
+        return jb.o_base + jh * jb.o_rs + (j - jh * jb.wc) * jb.o_cs;
+    };
 
     // ---- operand descriptors.  A: base = first latent row of the job; per-lane byte offset of its staging rows.
     const float* a_base = g.A + (long long)jb.n_first * g.a_rowstride;
@@ -78,7 +91,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         const int rc = r < m_valid ? r : m_valid - 1;              // ragged M: clamp loads, mask stores
         int q, j;
         split(rc, q, j);
-        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + g.pos_a[jb.pos_begin + j]) * 4u + (unsigned)c * 16u;
+        voff_a[s] = (unsigned)(q * (int)g.a_rowstride + pos_of_a(j)) * 4u + (unsigned)c * 16u;
     }
 #pragma unroll
     for (int s = 0; s < SB; ++s) {
@@ -158,7 +171,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
             ovalid[i][p] = r < m_valid;
             int q, j;
             split(ovalid[i][p] ? r : 0, q, j);
-            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + g.pos_out[jb.pos_begin + j]);
+            orow[i][p] = (unsigned)(q * (int)g.out_rowstride + pos_of_out(j));
         }
 
     // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk.

@@ -167,6 +167,24 @@ BatchedPlan make_batched(const LayerPlan& p) {
         cd.magic = (unsigned)(((1ULL << 31) + (unsigned)cd.pos_count - 1) / (unsigned)cd.pos_count);
         for (const auto& m : members[c]) { b.pos_a.push_back(m.first); b.pos_out.push_back(m.second); }
         for (const auto& t : sigs[c]) b.taps.push_back(TapEntry{t.first, t.second});
+        // is the class a grid?  smallest row length wc (a divisor of the position count) for which both tables are affine in
+        // (j / wc, j % wc)
+        const std::vector<std::pair<int, int>>& mem = members[c];
+        const int s = cd.pos_count;
+        for (int wc = 1; wc <= s && cd.wc == 0; ++wc) {
+            if (s % wc) continue;
+            const int a_cs = wc > 1 ? mem[1].first - mem[0].first : 0, o_cs = wc > 1 ? mem[1].second - mem[0].second : 0;
+            const int a_rs = s > wc ? mem[(size_t)wc].first - mem[0].first : 0, o_rs = s > wc ? mem[(size_t)wc].second - mem[0].second : 0;
+            bool ok = true;
+            for (int j = 0; j < s && ok; ++j)
+                ok = mem[(size_t)j].first == mem[0].first + (j / wc) * a_rs + (j % wc) * a_cs &&
+                     mem[(size_t)j].second == mem[0].second + (j / wc) * o_rs + (j % wc) * o_cs;
+            if (!ok) continue;
+            cd.wc = wc;
+            cd.wc_magic = (unsigned)(((1ULL << 31) + (unsigned)wc - 1) / (unsigned)wc);
+            cd.a_base = mem[0].first; cd.a_rs = a_rs; cd.a_cs = a_cs;
+            cd.o_base = mem[0].second; cd.o_rs = o_rs; cd.o_cs = o_cs;
+        }
         b.cls.push_back(cd);
     }
     return b;
@@ -264,6 +282,9 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         j.nchunks = cd.nchunks;
         j.magic = cd.magic;
         j.n_taps = cd.nchunks / (p.kch / 32);
+        j.wc = cd.wc; j.wc_magic = cd.wc_magic;
+        j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
+        j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
         if (cd.nchunks > 0) { j.tap0_a_off = p.taps[cd.tap_begin].a_off; j.tap0_w_off = p.taps[cd.tap_begin].w_off; }
         out.push_back(j);
     }

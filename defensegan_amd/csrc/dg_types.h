@@ -26,6 +26,13 @@ struct ClassDesc {
     int tap_begin;       // first entry of this class in the tap table (a_off relative to the row's pos_a base, >= 0)
     int nchunks;         // K chunks (32 floats each) of every tile of the class = taps * kch / 32
     unsigned magic;      // ceil(2^31 / s): m / s = mulhi(2 * m, magic) for m < 2^20 (also for s == 1)
+    // The positions of a class with taps are a rectangular sub-grid of the layer's maps: with wc positions per grid row,
+    // pos_a[j] = a_base + (j / wc) * a_rs + (j % wc) * a_cs and likewise pos_out -- the device computes them from these numbers
+    // (copied into every JobDesc) instead of fetching the tables: one dependent memory round trip less at every job start.
+    // wc = 0: not a grid (the zero-tap border class of the Batchnorm crop): the tables are read.
+    int wc;
+    unsigned wc_magic;   // ceil(2^31 / wc)
+    int a_base, a_rs, a_cs, o_base, o_rs, o_cs;
     int pad[3];
 };
 struct JobDesc {         // one workgroup = one job: (class, M range, column range, tile shape)
@@ -41,7 +48,12 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     unsigned magic;
     int tap0_a_off, tap0_w_off;
     int n_taps;          // nchunks / (kch / 32)
-    int pad[2];
+    int wc;              // the class's grid (ClassDesc): 0 = read the position tables
+    unsigned wc_magic;
+    // ---- second 64 bytes (the two scalar loads are issued together: one round trip)
+    int a_base, a_rs, a_cs, o_base, o_rs, o_cs;
+    int pad[10];
 };
+static_assert(sizeof(JobDesc) == 128, "two 64-byte scalar loads");
 
 }  // namespace dg

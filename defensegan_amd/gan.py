@@ -386,23 +386,39 @@ class DefenseGANBase(object):
                         continue
                 except Exception:
                     pass
+            # Caller batches of ``bs`` images decide what is cached (a batch whose pickles all exist is loaded, gan.py:504-557);
+            # the batches that have to be computed are handed to the engine in runs of consecutive batches of up to
+            # gan_defense.COALESCE_ROWS latent rows -- rows are independent without Batchnorm and z0 is keyed by (seed, global
+            # row), so the pickles hold the same bits as one engine call per batch would write, several times sooner at the
+            # reference's batch of 50 (tests/test_gpu_cache.py).  With USE_BN a batch is the unit of the statistics: no runs.
+            from . import gan_defense as _gd
+            per_call = bs if self.use_bn else _gd.engine_batch_images(bs, int(self.rec_rr), max(n, 1))
+            path_of = lambda i: os.path.join(pk_dir, "rec_{:07d}_l{}.pkl".format(i, targets[i]))
+            loaded = {}
             for start in range(0, n, bs):
-                end = min(n, start + bs)
-                paths = [os.path.join(pk_dir, "rec_{:07d}_l{}.pkl".format(i, targets[i])) for i in range(start, end)]
-                batch = None
+                paths = [path_of(i) for i in range(start, min(n, start + bs))]
                 if not test_again and all(os.path.exists(q) for q in paths):
                     try:
-                        batch = np.stack([pickle.load(open(q, "rb"), encoding="latin1") for q in paths])
+                        loaded[start] = np.stack([pickle.load(open(q, "rb"), encoding="latin1") for q in paths])
                     except Exception:
-                        batch = None
-                if batch is None:
-                    batch = self.reconstruct(np.asarray(images[start:end], np.float32),
-                                             seed=seed, first_row=start * int(self.rec_rr))
-                    batch = np.asarray(batch.cpu().numpy() if hasattr(batch, "cpu") else batch, np.float32)
-                    for q, r in zip(paths, batch):
-                        with open(q, "wb") as f:
-                            py2pickle.dump(r, f)
+                        pass
+            start = 0
+            while start < n:
+                if start in loaded:
+                    recs.append(loaded[start])
+                    start = min(n, start + bs)
+                    continue
+                end = min(n, start + bs)
+                while end < n and end not in loaded and end - start + min(bs, n - end) <= per_call:
+                    end = min(n, end + bs)
+                batch = self.reconstruct(np.asarray(images[start:end], np.float32),
+                                         seed=seed, first_row=start * int(self.rec_rr))
+                batch = np.asarray(batch.cpu().numpy() if hasattr(batch, "cpu") else batch, np.float32)
+                for i, r in zip(range(start, end), batch):
+                    with open(path_of(i), "wb") as f:
+                        py2pickle.dump(r, f)
                 recs.append(batch)
+                start = end
             all_recs = np.concatenate(recs).reshape([-1] + list(self.image_dim)) if recs else np.zeros([0] + list(self.image_dim), np.float32)
             rets[split] = [all_recs, np.asarray(targets[:n]), np.asarray(images[:n]).reshape([-1] + list(self.image_dim))]
         return rets

@@ -33,11 +33,43 @@ def _np(a):
     return a.detach().cpu().numpy()
 
 
+# Latent rows one engine call is filled up to when caller batches are coalesced: 12 500-row launches (the per-GPU shard of
+# BASELINE configs[4] in one call) run the loop at 0.852 of the fp32 peak, the reference's default 500 rows (BATCH_SIZE 50,
+# experiments/cfgs/gans/default.yml:2) at 0.656 (profiles/r04_exp_batch_sweep.txt, r04_bench_b50.json).
+COALESCE_ROWS = 12800
+
+
+def engine_batch_images(batch_size: int, rec_rr: int, n: int, target_rows: Optional[int] = None) -> int:
+    """Images per engine call when the caller's batches of ``batch_size`` images are coalesced: as many WHOLE caller batches as
+    fit ``target_rows`` (default ``COALESCE_ROWS``) latent rows (at least one), at most the ``n`` images there are."""
+    per_call = max(1, int(COALESCE_ROWS if target_rows is None else target_rows) // max(1, int(rec_rr)))
+    whole = max(1, per_call // max(1, int(batch_size)))
+    return max(1, min(int(n), whole * int(batch_size)))
+
+
+def rows_are_independent(reconstruct) -> bool:
+    """True when ``reconstruct`` is the bound ``reconstruct`` of an engine model without Batchnorm: every (image, restart) row
+    is then computed independently of the batch it is in -- GEMM tiles are never cut along K and z0 is keyed by the global row --
+    so ANY regrouping of the images into engine calls returns the same bits (tests/test_gpu_mnist.py
+    test_rows_are_independent_of_batching_and_deterministic).  With USE_BN the rows of a batch share its statistics
+    (tflib/ops/batchnorm.py:80-93) and the caller's batch boundaries are part of the result."""
+    owner = getattr(reconstruct, "__self__", None)
+    return owner is not None and hasattr(owner, "rec_rr") and hasattr(owner, "use_bn") and not bool(owner.use_bn)
+
+
 def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_images, test_labels,
                    batch_size: int, rec_rr: int = 1, compute_diffs: bool = True, seed: int = 11241990,
                    first_image: int = 0, same_init_z: Optional[np.ndarray] = None,
-                   verbose: bool = False, as_tensors: bool = False):
+                   verbose: bool = False, as_tensors: bool = False, coalesce=None):
     """Accuracy of ``classifier(reconstruct(x))`` over ``test_images`` + reconstruction errors.
+
+    ``batch_size`` is the caller's (the reference's ``BATCH_SIZE`` 50, default.yml:2).  It fixes what a batch MEANS -- the
+    latents of image i are row ``(first_image + i) * rec_rr + r`` of the seeded stream, ``same_init_z`` restarts at every batch
+    boundary -- but not how many images go to the engine at once: when the rows are independent (``rows_are_independent``:
+    an engine model without Batchnorm) consecutive caller batches are COALESCED into engine calls of up to ``COALESCE_ROWS``
+    latent rows, which returns the same bits several times faster (500-row launches run at 0.66 of the peak, 12 500-row ones at
+    0.85).  ``coalesce``: None = automatic as described, 0 / False = one engine call per caller batch (the reference's loop,
+    gan_defense.py:113-162), an integer = that many images per engine call (rounded down to whole caller batches).
 
     reconstruct : ``f(images, z_init_val=None, seed=..., first_row=...) -> reconstructions`` or None
                   (no defense: the classifier sees the inputs).
@@ -55,7 +87,16 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
     labels = _np(test_labels)
     if labels.ndim > 1:
         labels = labels.argmax(axis=-1)
-    nb_batches = int(math.ceil(float(n) / batch_size))
+    # images per engine call: whole caller batches (the z_init / seed bookkeeping below is per caller batch either way)
+    if coalesce is None:
+        coalesce = rows_are_independent(reconstruct)
+    if coalesce is True:
+        step = engine_batch_images(batch_size, rec_rr, max(n, 1))
+    elif coalesce:
+        step = max(1, int(coalesce) // int(batch_size)) * int(batch_size)
+    else:
+        step = int(batch_size)
+    nb_batches = int(math.ceil(float(n) / step))
     on_device = hasattr(classifier, "eval_batch")
     preds: List = []
     diffs: List = []
@@ -67,13 +108,15 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
         classifier._ensure()
         labels_dev = torch.from_numpy(np.ascontiguousarray(labels.astype(np.int32))).to(torch.device("cuda", classifier._device))
     for batch in range(nb_batches):
-        start = batch * batch_size
-        end = min(n, start + batch_size)          # last batch may be smaller (gan_defense.py:124-130)
+        start = batch * step
+        end = min(n, start + step)                # last batch may be smaller (gan_defense.py:124-130)
         x = test_images[start:end]
         if reconstruct is not None:
             kw = {}
             if same_init_z is not None:
-                kw["z_init_val"] = same_init_z[: (end - start) * rec_rr]
+                # --same_init (whitebox.py:181-183): every CALLER batch starts from the first rows of the same block
+                parts = [same_init_z[: (min(end, b0 + batch_size) - b0) * rec_rr] for b0 in range(start, end, batch_size)]
+                kw["z_init_val"] = parts[0] if len(parts) == 1 else _cat(parts)
             rec = reconstruct(x, seed=seed, first_row=(first_image + start) * rec_rr, **kw)
         else:
             rec = x
@@ -110,6 +153,13 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
         return correct, n, [torch.from_numpy(labels.astype(np.int32)), torch.from_numpy(preds_all.astype(np.int32)),
                             torch.from_numpy(diffs_all.astype(np.float32))]
     return correct, n, [labels.astype(np.int64), preds_all, diffs_all]
+
+
+def _cat(parts):
+    if isinstance(parts[0], np.ndarray):
+        return np.concatenate(parts)
+    import torch
+    return torch.cat(list(parts))
 
 
 def gather_shards(local_rows: np.ndarray, n_total: int, group=None, device=None) -> np.ndarray:

@@ -90,6 +90,17 @@ void dgp2_classes(void* h, int* out) {        // per class: pos_count, nchunks
     const Batched& b = *static_cast<Batched*>(h);
     for (size_t i = 0; i < b.plan.cls.size(); ++i) { out[2 * i] = b.plan.cls[i].pos_count; out[2 * i + 1] = b.plan.cls[i].nchunks; }
 }
+void dgp2_class_grids(void* h, int* out) {    // per class: wc (0 = not a grid), then whether the tables equal the grid formula
+    const Batched& b = *static_cast<Batched*>(h);
+    for (size_t i = 0; i < b.plan.cls.size(); ++i) {
+        const dg::ClassDesc& c = b.plan.cls[i];
+        int same = 1;
+        for (int j = 0; j < c.pos_count && c.wc; ++j)
+            same &= b.plan.pos_a[c.pos_begin + j] == c.a_base + (j / c.wc) * c.a_rs + (j % c.wc) * c.a_cs &&
+                    b.plan.pos_out[c.pos_begin + j] == c.o_base + (j / c.wc) * c.o_rs + (j % c.wc) * c.o_cs;
+        out[2 * i] = c.wc; out[2 * i + 1] = same;
+    }
+}
 int dgp2_make_jobs(void* h, int n_rows, int slots, double alpha) {
     Batched& b = *static_cast<Batched*>(h);
     b.jobs = dg::build_jobs(b.plan, n_rows, b.family, slots, alpha, dg::JobModel(), &b.predicted_us);
@@ -156,16 +167,26 @@ void dgp2_apply(void* h, const double* A, const double* W, const double* bias, d
             const int q = (int)(((unsigned long long)(jj << 1) * cd.magic) >> 32);
             const int j = (int)jj - q * cd.pos_count;
             const long long n = (long long)jb.n_first + q;
+            // the device's position arithmetic (dg_gemm.hip pos_of_a / pos_of_out): from the JOB RECORD's copy of the class grid
+            int pa, po;
+            if (jb.wc) {
+                const int jh = (int)(((unsigned long long)((unsigned)j << 1) * jb.wc_magic) >> 32);
+                pa = jb.a_base + jh * jb.a_rs + (j - jh * jb.wc) * jb.a_cs;
+                po = jb.o_base + jh * jb.o_rs + (j - jh * jb.wc) * jb.o_cs;
+            } else {
+                pa = p.pos_a[cd.pos_begin + j];
+                po = p.pos_out[cd.pos_begin + j];
+            }
             for (int c = 0; c < bn; ++c) {
                 const int col = jb.n0 + c;
                 double acc = 0.0;
                 for (int t = 0; t < n_taps; ++t) {
                     const dg::TapEntry& te = p.taps[cd.tap_begin + t];
-                    const double* a = A + n * p.a_rowstride + p.pos_a[cd.pos_begin + j] + te.a_off;
+                    const double* a = A + n * p.a_rowstride + pa + te.a_off;
                     const double* w = W + te.w_off + (long long)col * p.w_rowstride;
                     for (int k = 0; k < p.kch; ++k) acc += a[k] * w[k];
                 }
-                const long long o = n * p.out_rowstride + p.pos_out[cd.pos_begin + j] + col;
+                const long long o = n * p.out_rowstride + po + col;
                 if (mode == 1 || mode == 2) acc += bias[col];
                 if (mode == 2) acc = acc > 0 ? acc : 0;
                 if (mode == 3) acc = Out[o] > 0 ? acc : 0;

@@ -236,3 +236,32 @@ def test_kernel_trace_rows_are_labelled_with_the_bench_lines_layers(tmp_path):
     assert got[("F1", "lin_stationary_kernel<4, 2, false>")][0] == 70
     assert got[("UPD", "momentum_update_kernel")][0] == 70
     assert got[("", "gemm_batched_kernel<0, 3, 1> [candidate job lists, not kept]")][0] == 3
+
+
+def test_rank_cpus_are_disjoint_contiguous_slices():
+    cpus = set(range(64))
+    got = [bench.rank_cpus(r, 8, cpus) for r in range(8)]
+    assert got[0] == list(range(0, 8)) and got[3] == list(range(24, 32)) and got[7] == list(range(56, 64))
+    assert len({c for g in got for c in g}) == 64
+    assert bench.rank_cpus(1, 2, set(range(256))) == list(range(128, 136))          # at most 8 CPUs per rank
+    assert bench.rank_cpus(5, 8, {0, 1, 2}) == [0, 1, 2]                            # fewer CPUs than ranks: no empty set
+    phys, n = bench.physical_cores_one_socket()
+    assert n >= 1 and (phys is None or 1 <= phys <= n)
+
+
+def test_dominant_symbol_is_the_one_with_the_most_flop_ties_go_to_the_forward_layer():
+    """Generator.3's forward and backward run as two symbols with the same FLOP per launch and durations 0.05 % apart: the
+    roofline object must not depend on which of the two happened to take longer in the profiled step."""
+    def prof(f3_ms, b3_ms, n_b=199):
+        return [{"name": "F2@gemm<0, 2, 1>", "launches": 200, "ms": 54.0, "flops": 200 * 3.77e10},
+                {"name": "F3@gemm<1, 2, 1>", "launches": 200, "ms": f3_ms, "flops": 200 * 4.29e10},
+                {"name": "T5fb@tail", "launches": 199, "ms": 10.2, "flops": 199 * 2.9e9},
+                {"name": "B3@gemm<0, 3, 1>", "launches": n_b, "ms": b3_ms, "flops": n_b * 4.29e10},
+                {"name": "UPD@upd", "launches": 199, "ms": 1.2, "flops": 0.0}]
+    for f3, b3 in ((62.06, 62.03), (62.00, 62.40)):
+        _, r = bench.roofline_from_profile(prof(f3, b3), "mnist", 256, 10, 133.0, None)
+        assert r["kernel"] == "gemm<1, 2, 1>" and r["layers"] == ["F3"]
+        assert [m["layer"] for m in r["mfma_layers"][:3]] in (["F3", "B3", "F2"], ["B3", "F3", "F2"])
+        assert abs(r["achieved"] - 200 * 4.29e10 / (f3 * 1e-3) / 1e12) < 0.01
+    _, r = bench.roofline_from_profile(prof(62.0, 62.0, n_b=200), "mnist", 256, 10, 133.0, None)      # exact tie -> forward
+    assert r["layers"] == ["F3"]

@@ -172,12 +172,29 @@ def test_reconstruct_dataset_cache_layout(tmp_path):
     assert sorted(p.name for p in d.iterdir())[0] == "rec_0000000_l0.pkl" and len(list(d.iterdir())) == 7
     np.testing.assert_allclose(pickle.load(open(d / "rec_0000004_l1.pkl", "rb")), x[4] * 0.5)
     _assert_python2_era_numpy_can_unpickle((d / "rec_0000004_l1.pkl").read_bytes(), n_objects=1)
-    assert [c[:2] for c in calls] == [(3, 0), (3, 6), (1, 12)]
+    # caller batches of 3 decide what is cached; what has to be computed goes to the engine in runs of consecutive batches
+    # (rows are independent without Batchnorm): here all seven images in one call, global row 0
+    assert [c[:2] for c in calls] == [(7, 0)]
     np.testing.assert_allclose(out["test"][0], x * 0.5)
     n_before = len(calls)
     again = gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)       # served from the cache
     assert len(calls) == n_before
     np.testing.assert_allclose(again["test"][0], x * 0.5)
+    # one missing pickle: exactly its caller batch (images 3..5, global row 6) is recomputed, the cached neighbours are not
+    (d / "rec_0000004_l1.pkl").unlink()
+    gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)
+    assert [c[:2] for c in calls[n_before:]] == [(3, 6)]
+    # two neighbouring batches missing: one run; with Batchnorm the batch is the unit of the statistics: one call per batch
+    (d / "rec_0000004_l1.pkl").unlink(); (d / "rec_0000006_l0.pkl").unlink()
+    n_mid = len(calls)
+    gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3)
+    assert [c[:2] for c in calls[n_mid:]] == [(4, 6)]
+    gan.use_bn = True
+    n_mid = len(calls)
+    gan.reconstruct_dataset({"test": (x, y)}, str(tmp_path), batch_size=3, test_again=True)
+    assert [c[:2] for c in calls[n_mid:]] == [(3, 0), (3, 6), (1, 12)]
+    gan.use_bn = False
+    n_before = len(calls)
     # a whole-split feats.pkl (gan.py:484-496) takes precedence over the per-image pickles
     feats = tmp_path / "recs_rr2_lr10.00000_iters5" / "test" / "feats.pkl"
     with open(feats, "wb") as f:
@@ -275,3 +292,55 @@ def test_celeba_lazy_loader_crop_bytescale_resize(tmp_path):
     assert lab.shape == (182637 - 162771 + 1,) and lab[0] == (1 if 162771 % 3 == 0 else 0) and set(lab.tolist()) == {0, 1}
     with pytest.raises(ValueError):
         datasets.load_celeba_split(str(d), "all")
+
+
+class _FakeModel(object):
+    """Stand-in with the attributes ``rows_are_independent`` looks at; its output depends on the image and on the z0 row the
+    harness names for it (first_row / z_init_val), never on the batch it arrives in -- like the engine without Batchnorm."""
+
+    def __init__(self, use_bn=False, rec_rr=3):
+        self.use_bn, self.rec_rr, self.calls = use_bn, rec_rr, []
+
+    def reconstruct(self, x, seed=None, first_row=None, z_init_val=None):
+        x = np.asarray(x)
+        self.calls.append((len(x), first_row))
+        rows = first_row + np.arange(len(x)) * self.rec_rr                 # the global latent row of each image's first restart
+        z = np.zeros(len(x)) if z_init_val is None else np.asarray(z_init_val).reshape(len(x), self.rec_rr, -1)[:, 0, 0]
+        return np.clip(x * 0.5 + (rows % 7)[:, None, None, None] * 0.01 + z[:, None, None, None], 0, 1).astype(np.float32)
+
+
+def test_engine_batch_images_takes_whole_caller_batches():
+    assert gd.engine_batch_images(50, 10, 10000) == 1250           # the reference's batch: 25 caller batches = 12 500 rows
+    assert gd.engine_batch_images(50, 10, 120) == 120              # never more than there is
+    assert gd.engine_batch_images(256, 10, 10000) == 1280
+    assert gd.engine_batch_images(2000, 10, 10000) == 2000         # a caller batch above the target stays whole
+    assert gd.engine_batch_images(7, 1, 10000, target_rows=100) == 98
+
+
+def test_model_eval_gan_coalesces_caller_batches_without_changing_the_result():
+    rs = np.random.RandomState(1)
+    x = rs.rand(130, 4, 4, 1).astype(np.float32) * 2
+    y = rs.randint(0, 2, 130)
+    per = _FakeModel()
+    c0, n0, roc0 = gd.model_eval_gan(per.reconstruct, classifier, x, y, batch_size=10, rec_rr=3, coalesce=False)
+    assert [k for k, _ in per.calls] == [10] * 13 and [fr for _, fr in per.calls] == [30 * i for i in range(13)]
+    auto = _FakeModel()
+    c1, n1, roc1 = gd.model_eval_gan(auto.reconstruct, classifier, x, y, batch_size=10, rec_rr=3)
+    assert auto.calls == [(130, 0)]                                  # one engine call: 390 rows fit the target
+    assert (c1, n1) == (c0, n0) and all(np.array_equal(a, b) for a, b in zip(roc0, roc1))
+    some = _FakeModel()
+    c2, _, roc2 = gd.model_eval_gan(some.reconstruct, classifier, x, y, batch_size=10, rec_rr=3, coalesce=45, first_image=20)
+    assert [k for k, _ in some.calls] == [40, 40, 40, 10] and [fr for _, fr in some.calls] == [60, 180, 300, 420]
+    # --same_init: every CALLER batch restarts from the head of the block, also inside a coalesced call (ragged tail included)
+    zi = rs.rand(10 * 3, 2).astype(np.float32) * 0.05
+    a, b = _FakeModel(), _FakeModel()
+    ra = gd.model_eval_gan(a.reconstruct, classifier, x[:25], y[:25], batch_size=10, rec_rr=3, same_init_z=zi, coalesce=False)
+    rb = gd.model_eval_gan(b.reconstruct, classifier, x[:25], y[:25], batch_size=10, rec_rr=3, same_init_z=zi)
+    assert b.calls == [(25, 0)] and ra[0] == rb[0] and all(np.array_equal(p, q) for p, q in zip(ra[2], rb[2]))
+    # Batchnorm couples the rows of a batch, a plain function says nothing about its rows: the caller's batches are kept
+    bn = _FakeModel(use_bn=True)
+    gd.model_eval_gan(bn.reconstruct, classifier, x, y, batch_size=10, rec_rr=3)
+    assert [k for k, _ in bn.calls] == [10] * 13
+    calls = []
+    gd.model_eval_gan(fake_reconstruct(calls), classifier, x, y, batch_size=10, rec_rr=3)
+    assert [k for k, _ in calls] == [10] * 13

@@ -33,6 +33,7 @@ def lib():
     l.dgp2_free.argtypes = [C.c_void_p]
     l.dgp2_info.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
     l.dgp2_classes.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_class_grids.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp2_make_jobs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double]
     l.dgp2_predicted_us.restype = C.c_double
     l.dgp2_predicted_us.argtypes = [C.c_void_p]
@@ -417,3 +418,26 @@ def test_committed_tuning_files_describe_lists_this_planner_builds(lib):
         assert seen == set(table), (wl, seen)
     if not checked:
         pytest.skip("no committed tuning files")
+
+
+def test_every_class_with_taps_is_a_rectangular_grid(lib):
+    """The device computes a position's offsets from the job record (ClassDesc wc / a_base / a_rs / a_cs / o_*, dg_types.h) instead
+    of reading the position tables: holds for every class of every GEMM layer of both generators (with and without Batchnorm's
+    padded maps) -- the formula reproduces the tables exactly; a class that is not a grid (none with taps) keeps wc = 0."""
+    layers = [("deconv_fwd", (4, 4, 7, 7, 256, 128, 128)), ("deconv_fwd", (7, 7, 14, 14, 128, 64, 64)),
+              ("deconv_bwd", (4, 4, 7, 7, 256, 128, 256)), ("deconv_bwd", (7, 7, 14, 14, 128, 64, 128)),
+              ("deconv_fwd", (4, 4, 8, 8, 256, 128, 128)), ("deconv_fwd", (8, 8, 16, 16, 128, 64, 64)),
+              ("deconv_fwd", (16, 16, 32, 32, 64, 64, 64)), ("deconv_bwd", (4, 4, 8, 8, 256, 128, 256)),
+              ("deconv_bwd", (8, 8, 16, 16, 128, 64, 128)), ("deconv_bwd", (16, 16, 32, 32, 64, 64, 64)),
+              ("deconv_fwd", (4, 4, 8, 8, 256, 128, 128)), ("deconv_bwd", (7, 8, 14, 14, 128, 64, 128)),
+              ("linear_fwd", (128, 4096, 4096)), ("linear_bwd", (128, 4096, 16, 128))]
+    for kind, p in layers:
+        h1, h2, info, b = batched(lib, kind, *p)
+        g = (C.c_int * (2 * b["n_classes"]))()
+        lib.dgp2_class_grids(h2, g)
+        for i, (s, k) in enumerate(b["classes"]):
+            wc, same = g[2 * i], g[2 * i + 1]
+            assert same == 1
+            if k > 0:
+                assert wc >= 1 and s % wc == 0, (kind, p, i, s, wc)
+        lib.dgp2_free(h2); lib.dgp_free(h1)

@@ -15,16 +15,21 @@ from defensegan_amd.gan import dataset_gan_dict
 op = sys.argv[1] if len(sys.argv) > 1 else "F2"
 arch, B, R = "mnist", 256, 10
 opts = {}
+tuning = dump = None
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     if k == "arch": arch = v
     elif k == "B": B = int(v)
+    elif k == "tuning": tuning = v          # a dg_export_tuning text (profiles/rNN_tuning_<arch>.txt): trace THOSE lists
+    elif k == "dump": dump = v              # .npz of the raw records (block, start, end, hw id, chunks) + the tuning text
     else: opts[k] = v
 a = archs.make_arch(arch)
 gan = dataset_gan_dict[arch](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=R, rec_iters=3, device=0)
 gan.set_weights(synth.make_weights(arch, seed=1234, gain=2.0))
 for k, v in opts.items():
     gan.set_option(k, v)
+if tuning:
+    gan.import_tuning(open(tuning).read())
 x = gan.generate(gan.init_latents(B, seed=1))
 x = torch.clamp(x + 0.3 * torch.sign(torch.randn_like(x)), a.in_lo, a.in_hi)
 gan.reconstruct(x, seed=1)                       # builds / tunes the job lists
@@ -34,6 +39,9 @@ t = gan.debug_read("job_trace", 65536 * 4 * 2).cpu().numpy().view(np.int64).resh
 block = np.nonzero(t[:, 1] > 0)[0]
 t = t[t[:, 1] > 0]
 start, end, hwid, chunks = t[:, 0], t[:, 1], t[:, 2], t[:, 3]
+if dump:
+    np.savez_compressed(dump, block=block, start=start, end=end, hwid=hwid, chunks=chunks, op=op, arch=arch, rows=B * R,
+                        tuning=gan.export_tuning())
 t0 = start.min()
 s_us, e_us = (start - t0) / 100.0, (end - t0) / 100.0
 span = e_us.max()
