@@ -10,7 +10,7 @@ from tests.helpers import clean_targets, make_gan
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("arch,wseed,B,nb", [("fmnist", 4321, 256, 32), ("celeba", 1234, 128, 8)])
+@pytest.mark.parametrize("arch,wseed,B,nb", [("fmnist", 4321, 256, 32), ("celeba", 1234, 128, 16)])
 def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
     R, L = 10, 200
     a = archs.make_arch(arch)

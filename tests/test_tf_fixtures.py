@@ -139,3 +139,126 @@ def test_checkpoint_reader_against_a_real_saver_file(ckpt):
     assert sorted(got) == sorted(want)
     for k in want:
         assert np.array_equal(np.asarray(got[k]).reshape(want[k].shape), want[k]), k
+
+
+# ---- a committed fixture must be USABLE: a present-but-malformed file fails (it must not look like "no fixtures: skipped") ----
+def validate_fixture(path):
+    """Raises AssertionError naming what is wrong with a tests/golden/tf_<case>.npz: unknown case name, missing arrays, shapes
+    that do not fit the case, or inputs that are not the ones the kit generates for that case (stale kit / edited file)."""
+    kit = _kit()
+    name = os.path.basename(path)[3:-4]
+    specs = [c for c in kit.CASES if c[0] == name]
+    assert specs, "%s: no case '%s' in tools/make_tf_fixtures.py CASES" % (path, name)
+    _, arch, wseed, gain, bias_range, B, R, adv, zseed = specs[0]
+    try:
+        f = np.load(path)
+        files = set(f.files)
+    except Exception as e:                                                   # not an npz at all
+        raise AssertionError("%s: unreadable (%s)" % (path, e))
+    for k in ("x", "z0", "iters"):
+        assert k in files, "%s: array '%s' missing" % (path, k)
+    dim = kit.image_dim(arch)
+    assert list(f["x"].shape) == [B] + dim, "%s: x has shape %r, case %s needs %r" % (path, f["x"].shape, name, [B] + dim)
+    assert f["z0"].shape == (B * R, kit.LATENT), "%s: z0 has shape %r" % (path, f["z0"].shape)
+    zt, z0 = kit.make_latents(zseed, B, R)
+    assert np.array_equal(f["z0"], z0), "%s: z0 is not the kit's draw for this case (stale kit or edited fixture)" % path
+    iters = [int(v) for v in f["iters"]]
+    assert iters and all(v >= 1 for v in iters), "%s: iters = %r" % (path, iters)
+    P = int(np.prod(dim))
+    for L in iters:
+        for k, shape in (("rec_%d" % L, B * P), ("rows_%d" % L, B * R * P), ("loss_%d" % L, B * R), ("idx_%d" % L, B)):
+            assert k in files, "%s: array '%s' missing" % (path, k)
+            assert f[k].size == shape, "%s: '%s' has %d values, expected %d" % (path, k, f[k].size, shape)
+        assert np.isfinite(f["rows_%d" % L]).all() and np.isfinite(f["loss_%d" % L]).all(), "%s: non-finite outputs at L = %d" % (path, L)
+        idx = np.asarray(f["idx_%d" % L]).reshape(B)
+        assert ((idx >= 0) & (idx < R)).all(), "%s: idx_%d outside [0, R)" % (path, L)
+
+
+@pytest.mark.parametrize("path", _fixtures() or [None])
+def test_committed_tf_fixtures_are_well_formed(path):
+    if path is None:
+        pytest.skip(NO_FIXTURES)
+    validate_fixture(path)
+
+
+def test_a_malformed_fixture_fails_instead_of_skipping(tmp_path):
+    """The validator the committed fixtures go through rejects: an unknown case name, a truncated file, missing arrays, a z0
+    that is not the kit's draw -- each with an AssertionError (a failure), never a skip."""
+    kit = _kit()
+    name, arch, wseed, gain, bias_range, B, R, adv, zseed = kit.CASES[0]
+    zt, z0 = kit.make_latents(zseed, B, R)
+    P = int(np.prod(kit.image_dim(arch)))
+    good = {"x": np.zeros([B] + kit.image_dim(arch), np.float32), "z0": z0, "iters": np.array([1]),
+            "rec_1": np.zeros((B, P), np.float32), "rows_1": np.zeros((B * R, P), np.float32), "loss_1": np.zeros(B * R, np.float32),
+            "idx_1": np.zeros(B, np.int64)}
+    ok = str(tmp_path / ("tf_%s.npz" % name))
+    np.savez(ok, **good)
+    validate_fixture(ok)                                                     # the well-formed one passes
+    bad = []
+    p1 = str(tmp_path / "tf_no_such_case.npz"); np.savez(p1, **good); bad.append(p1)
+    p2 = str(tmp_path / "a" / ("tf_%s.npz" % name)); os.makedirs(os.path.dirname(p2)); open(p2, "wb").write(open(ok, "rb").read()[:100]); bad.append(p2)
+    p3 = str(tmp_path / "b" / ("tf_%s.npz" % name)); os.makedirs(os.path.dirname(p3)); np.savez(p3, **{k: v for k, v in good.items() if k != "rows_1"}); bad.append(p3)
+    p4 = str(tmp_path / "c" / ("tf_%s.npz" % name)); os.makedirs(os.path.dirname(p4)); np.savez(p4, **dict(good, z0=z0 + 1)); bad.append(p4)
+    p5 = str(tmp_path / "d" / ("tf_%s.npz" % name)); os.makedirs(os.path.dirname(p5)); np.savez(p5, **dict(good, idx_1=np.full(B, R))); bad.append(p5)
+    for q in bad:
+        with pytest.raises(AssertionError):
+            validate_fixture(q)
+
+
+def test_the_kit_is_python_2_7_syntax():
+    """tools/make_tf_fixtures.py must run UNMODIFIED under Python 2.7 (the reference's interpreter; not installed here, so it
+    cannot be py_compiled by one): its syntax tree holds none of the constructs Python 2.7 rejects, it imports print_function,
+    and it compiles here with every warning an error."""
+    import ast
+    import tokenize
+    import warnings
+    path = os.path.join(ROOT, "tools", "make_tf_fixtures.py")
+    src = open(path).read()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        tree = ast.parse(src, path)
+        compile(src, path, "exec")
+    py3_only = (ast.JoinedStr, ast.AnnAssign, ast.Nonlocal, ast.YieldFrom, ast.AsyncFunctionDef, ast.AsyncFor, ast.AsyncWith,
+                ast.Await, ast.MatMult, ast.NamedExpr)
+    bad = []
+    future_print = False
+    for node in ast.walk(tree):
+        if isinstance(node, py3_only):
+            bad.append((type(node).__name__, node.lineno))
+        if isinstance(node, (ast.FunctionDef, ast.Lambda)):
+            a = node.args
+            if a.kwonlyargs or getattr(a, "posonlyargs", None):
+                bad.append(("keyword-only / positional-only arguments", node.lineno))
+            if isinstance(node, ast.FunctionDef) and (node.returns is not None or any(x.annotation is not None for x in a.args)):
+                bad.append(("annotations", node.lineno))
+        if isinstance(node, ast.Raise) and node.cause is not None:
+            bad.append(("raise ... from", node.lineno))
+        if isinstance(node, ast.Call):
+            if isinstance(node.func, ast.Name) and node.func.id == "super" and not node.args:
+                bad.append(("zero-argument super()", node.lineno))
+            if sum(isinstance(x, ast.Starred) for x in node.args) > 1 or sum(k.arg is None for k in node.keywords) > 1:
+                bad.append(("PEP 448 unpacking in a call", node.lineno))
+            if isinstance(node.func, ast.Name) and node.func.id == "open" and any(k.arg in ("encoding", "newline") for k in node.keywords):
+                bad.append(("open(encoding=)", node.lineno))
+        if isinstance(node, ast.Dict) and any(k is None for k in node.keys):
+            bad.append(("{**d}", node.lineno))
+        if isinstance(node, (ast.List, ast.Tuple, ast.Set)) and isinstance(getattr(node, "ctx", None), ast.Load) and any(isinstance(x, ast.Starred) for x in node.elts):
+            bad.append(("[*a]", node.lineno))
+        if isinstance(node, ast.Assign) and any(isinstance(t, (ast.Tuple, ast.List)) and any(isinstance(e, ast.Starred) for e in t.elts) for t in node.targets):
+            bad.append(("a, *b = ...", node.lineno))
+        if isinstance(node, ast.ClassDef) and node.keywords:
+            bad.append(("class keywords (metaclass=)", node.lineno))
+        if isinstance(node, ast.ImportFrom) and node.module == "__future__" and any(n.name == "print_function" for n in node.names):
+            future_print = True
+        if isinstance(node, ast.Name) and node.id in ("FileNotFoundError", "PermissionError", "ModuleNotFoundError", "nonlocal"):
+            bad.append((node.id, node.lineno))
+    assert future_print, "from __future__ import print_function is missing"
+    with open(path, "rb") as fh:
+        for tok in tokenize.tokenize(fh.readline):
+            if tok.type == tokenize.NUMBER and "_" in tok.string:
+                bad.append(("1_000 literal", tok.start[0]))
+            if tok.type == tokenize.STRING and tok.string[:2].lower() in ("f'", 'f"', "rb", "br") and tok.string[0].lower() == "f":
+                bad.append(("f-string", tok.start[0]))
+            if tok.type == tokenize.OP and tok.string in ("->", ":=", "@="):
+                bad.append((tok.string, tok.start[0]))
+    assert not bad, bad
