@@ -77,6 +77,7 @@ struct JobList {
     int snake = 0;                 // 1 = every other round of #CUs jobs reversed (boustrophedon)
     double slack = 0.0;            // the cutting threshold the list was built with (dg_plan.h build_jobs)
     double taper = 0.0;            // JobModel::taper the list was built with
+    int prio = 0;                  // 1 = wave priorities by predicted job length (dg_plan.h assign_priorities)
     double xcd_head = 0.0;         // head fraction of the XCD-locality order
     double predicted_us = 0.0;     // simulated makespan of the cost model
     double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
@@ -153,6 +154,9 @@ struct dg_handle {
     int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
     int job_taper_tune = 1;        // 1 = tapered lists (dg_plan.h JobModel::taper) are among the timed candidates
+    // Wave priorities by predicted job length (dg_types.h JobDesc::prio): 1 = the best lists of the timing are timed again with
+    // priorities and the faster form is kept (default), 0 = never, 2 = every list carries them (measurement, bit-identity tests)
+    int job_prio = 1;
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
     // launch took the same time (465 vs 466 us), fetched the same bytes across the L2/fabric boundary (907 vs 910 MB raw) and
@@ -537,6 +541,10 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             jm.taper = tapers[k];
             c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
                                     jm, &c.jl.predicted_us, lvl);
+            if (h->job_prio >= 2) {
+                c.jl.prio = 1;
+                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], jm, 1);
+            }
             auto add = [&](Cand&& x) {
                 for (const Cand& o : cands)
                     if (o.jl.min_level == x.jl.min_level && o.jobs.size() == x.jobs.size() &&
@@ -626,6 +634,28 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             if (level_best[c.jl.min_level] > 1.02f * plain_best) { c.ms = 1e30f; continue; }      // never uploaded, never kept
             ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
         }
+        if (ok && h->job_prio == 1) {
+            // the three fastest lists so far, once more with wave priorities by predicted job length (same jobs, same order)
+            std::vector<size_t> top;
+            for (size_t i = 0; i < cands.size(); ++i) if (cands[i].ms < 1e29f) top.push_back(i);
+            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
+            if (top.size() > 3) top.resize(3);
+            for (size_t k = 0; ok && k < top.size(); ++k) {
+                Cand c;
+                c.jl = cands[top[k]].jl;
+                c.jl.d_jobs = nullptr;
+                c.jl.prio = 1;
+                c.jobs = cands[top[k]].jobs;
+                dg::JobModel jm = h->job_model;
+                jm.taper = c.jl.taper;
+                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][c.jl.min_level], jm, 1);
+                bool any = false;
+                for (const dg::JobDesc& j : c.jobs) any = any || j.prio != 0;
+                if (!any) continue;
+                ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+                cands.push_back(std::move(c));
+            }
+        }
         if (ok) {
             for (size_t i = 0; i < cands.size(); ++i)
                 if (cands[i].ms < cands[best].ms) best = i;
@@ -664,8 +694,8 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             if (getenv("DG_TUNE_VERBOSE")) {
                 for (size_t i = 0; i < cands.size(); ++i)
                     if (cands[i].ms < 1e29f)
-                    fprintf(stderr, "[dg tune] %s rows %d level %d%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake ? " snake" : "      ",
+                    fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
                             i == best ? "  <- kept" : "");
             }
@@ -1544,6 +1574,7 @@ int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
             dg::TuneRecord r;
             r.op = op.name; r.n_rows = jl.n_rows; r.min_level = jl.min_level; r.slack = jl.slack; r.snake = jl.snake;
             r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us; r.taper = jl.taper;
+            r.prio = jl.prio;
             out += dg::format_tune_record(r);
         }
     };
@@ -1581,11 +1612,11 @@ int dg_import_tuning(dg_handle* h, const char* text) {
         }
         GemmOp* op = nullptr;
         for (GemmOp* o : ops) if (o->name == r.op) op = o;
-        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2)
+        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2 || r.prio < 0 || r.prio > 1)
             return fail(DG_E_INVALID, "tuning record for unknown layer '%s' / bad row count %d / level %d", r.op.c_str(), r.n_rows, r.min_level);
         JobList jl;
         jl.n_rows = r.n_rows; jl.min_level = r.min_level; jl.slack = r.slack; jl.snake = r.snake; jl.xcd_order = r.xcd_order;
-        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper;
+        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper; jl.prio = r.prio;
         const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(op->bplan, op->family, h->cu_count, h->job_slots_per_cu[op->family][r.min_level],
                                                                    r, h->job_model, &jl.predicted_us);
         if ((int)jobs.size() != r.n_jobs)
@@ -1732,7 +1763,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
         k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
-        k == "jobs.taper_tune") {
+        k == "jobs.taper_tune" || k == "jobs.prio") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1744,6 +1775,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.xcd_head") h->job_xcd_head = v;
         else if (k == "jobs.taper") h->job_model.taper = v;
         else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
+        else if (k == "jobs.prio") h->job_prio = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
         drop_job_lists(h);

@@ -310,6 +310,14 @@ __global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (MINLEVEL == 1 ? 3 : 4)) v
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const JobDesc jb = g.jobs[blockIdx.x];
     const int shape = __builtin_amdgcn_readfirstlane(jb.shape);
+    // wave priority by predicted job length (dg_types.h JobDesc::prio; s_setprio takes an immediate).  Lists without
+    // priorities carry 0 everywhere: three scalar compares, not taken.
+    {
+        const int pr = __builtin_amdgcn_readfirstlane(jb.prio);
+        if (pr == 3) __builtin_amdgcn_s_setprio(3);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    }
     if constexpr (FAM == 0) {
         if constexpr (MINLEVEL <= 0) {
             if (shape == 0) { run_job<2, 2, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }

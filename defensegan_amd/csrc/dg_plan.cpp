@@ -321,10 +321,23 @@ void snake_order(std::vector<JobDesc>& jobs, int cus) {
         std::reverse(jobs.begin() + g0, jobs.begin() + std::min(jobs.size(), g0 + (size_t)cus));
 }
 
+void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode) {
+    double longest = 0.0;
+    for (const JobDesc& j : jobs) longest = std::max(longest, job_us(p, j, family, slots, model));
+    for (JobDesc& j : jobs) {
+        int pr = 0;
+        if (mode && longest > 0.0) {
+            pr = (int)(4.0 * job_us(p, j, family, slots, model) / longest);
+            pr = pr > 3 ? 3 : (pr < 0 ? 0 : pr);
+        }
+        j.prio = pr;
+    }
+}
+
 std::string format_tune_record(const TuneRecord& r) {
     char line[256];
-    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f %.17g\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
-             r.xcd_head, r.n_jobs, r.measured_us, r.taper);
+    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f %.17g %d\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
+             r.xcd_head, r.n_jobs, r.measured_us, r.taper, r.prio);
     return line;
 }
 
@@ -343,7 +356,14 @@ bool parse_tune_record(const char** pp, TuneRecord* r) {
         while (*q == ' ' || *q == '\t') ++q;
         int u2 = 0;
         double tp = 0.0;
-        if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%lf%n", &tp, &u2) == 1 && u2 > 0) { t.taper = tp; used = (int)(q - p) + u2; }
+        if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%lf%n", &tp, &u2) == 1 && u2 > 0) {
+            t.taper = tp; used = (int)(q - p) + u2;
+            // optional eleventh field: the priority mode
+            q = p + used;
+            while (*q == ' ' || *q == '\t') ++q;
+            int pr = 0, u3 = 0;
+            if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%d%n", &pr, &u3) == 1 && u3 > 0) { t.prio = pr; used = (int)(q - p) + u3; }
+        }
     }
     t.op = name;
     *r = t;
@@ -358,6 +378,7 @@ std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus,
     std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);
     if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
     if (r.snake) snake_order(jobs, cus);
+    if (r.prio) assign_priorities(p, jobs, family, cus * slots_per_cu, m, r.prio);
     return jobs;
 }
 

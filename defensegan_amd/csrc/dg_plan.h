@@ -101,7 +101,8 @@ struct TuneRecord {
     double xcd_head = 0.0;
     int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
     double measured_us = 0.0;  // informational
-    double taper = 0.0;        // JobModel::taper the list was built with (last field of the line; absent in round-4a texts = 0)
+    double taper = 0.0;        // JobModel::taper the list was built with (tenth field of the line; absent in round-4a texts = 0)
+    int prio = 0;              // 1 = wave priorities by predicted job length (assign_priorities; eleventh field, absent = 0)
 };
 std::string format_tune_record(const TuneRecord& r);                 // one line, '\n'-terminated
 // Parses the record at *p and advances *p behind it; false on a malformed record (nothing consumed) or at the end of the text.
@@ -110,6 +111,9 @@ bool parse_tune_record(const char** p, TuneRecord* r);
 std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus, int slots_per_cu, const TuneRecord& r,
                                       const JobModel& model = JobModel(), double* predicted_us = nullptr);
 void snake_order(std::vector<JobDesc>& jobs, int cus);
+// JobDesc::prio by predicted length: a job whose predicted duration (cost model, at the list's residency) is in the top quarter
+// of the longest job's gets priority 3, the next quarter 2, ... ; mode 0 clears them.  Order and arithmetic are untouched.
+void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode);
 
 // Makespan (microseconds) of greedy list scheduling of `jobs` in order on `slots` servers of 1/slots of the chip each.
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model);

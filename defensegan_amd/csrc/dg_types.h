@@ -52,7 +52,13 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     unsigned wc_magic;
     // ---- second 64 bytes (the two scalar loads are issued together: one round trip)
     int a_base, a_rs, a_cs, o_base, o_rs, o_cs;
-    int pad[10];
+    // Wave priority of the job's workgroup (s_setprio, 0..3).  A job of many K chunks is one dependent chain: sharing a SIMD's
+    // matrix pipe equally with its neighbours it lasts most of the launch (CelebA's 4x4 <- 8x8 backward at 1280 rows: 100-chunk
+    // jobs of 170 us in a 204 us launch, whatever their tile size), and what is dispatched behind it can only start then.  With
+    // priority by predicted length the long jobs take the pipe first and end early, the short ones -- which have slack -- fill in:
+    // completion times spread out instead of piling up at the end of the first dispatch round.  Results cannot change.
+    int prio;
+    int pad[9];
 };
 static_assert(sizeof(JobDesc) == 128, "two 64-byte scalar loads");
 

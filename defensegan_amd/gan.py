@@ -519,9 +519,9 @@ class DefenseGANBase(object):
 
 def tuning_text_id(text: str) -> str:
     """12 hex digits naming the job lists a dg_export_tuning text describes.  A record is
-    ``op n_rows min_level slack snake xcd_order xcd_head n_jobs measured_us [taper]`` (dg_plan.cpp format_tune_record):
+    ``op n_rows min_level slack snake xcd_order xcd_head n_jobs measured_us [taper [prio]]`` (dg_plan.cpp format_tune_record):
     every field but ``measured_us`` (index 8, informational: two timings of the same list differ) enters the id, the taper
-    -- which does change the list -- included; a 9-field record of an older text is a taper of 0."""
+    and the priority mode -- which do change the list -- included; fields an older text lacks count as 0."""
     import hashlib
     lines = text.strip().splitlines()
     keys = []
@@ -531,7 +531,8 @@ def tuning_text_id(text: str) -> str:
             keys.append(" ".join(f))         # not a record this build writes: hashed as it is
             continue
         taper = f[9] if len(f) > 9 else "0"
-        keys.append(" ".join(f[:8] + ["%.17g" % float(taper)]))
+        prio = f[10] if len(f) > 10 else "0"                  # eleventh field (round 5): wave priorities by job length
+        keys.append(" ".join(f[:8] + ["%.17g" % float(taper), str(int(prio))]))
     return hashlib.sha256("\n".join(sorted(keys) if keys else lines).encode()).hexdigest()[:12]
 
 

@@ -132,6 +132,24 @@ int dgp2_make_recorded(void* h, const char* op, int n_rows, int cus, int slots_p
     std::memcpy(line, t.c_str(), t.size() + 1);
     return r.n_jobs;
 }
+// Wave priorities by predicted job length on the current list (dg_plan.h assign_priorities); out = the priority of every job
+void dgp2_assign_priorities(void* h, int cus, int slots_per_cu, int mode, int* out) {
+    Batched& b = *static_cast<Batched*>(h);
+    dg::assign_priorities(b.plan, b.jobs, b.family, cus * slots_per_cu, dg::JobModel(), mode);
+    for (size_t i = 0; i < b.jobs.size(); ++i) out[i] = b.jobs[i].prio;
+}
+// The current list's record line with the given priority mode (the list itself is left alone)
+int dgp2_format_with_prio(void* h, const char* line_in, int prio, char* line, int cap) {
+    const char* p = line_in;
+    dg::TuneRecord r;
+    if (!dg::parse_tune_record(&p, &r)) return -1;
+    r.prio = prio;
+    const std::string t = dg::format_tune_record(r);
+    if ((int)t.size() + 1 > cap) return -1;
+    std::memcpy(line, t.c_str(), t.size() + 1);
+    (void)h;
+    return 0;
+}
 // Parses `text` (record lines), rebuilds the list of its record number `which` and compares it byte for byte with the
 // current list: 1 equal, 0 different, -1 malformed / no such record, -2 the record's job count does not match.
 int dgp2_rebuild_matches(void* h, const char* text, int which, int cus, int slots_per_cu) {

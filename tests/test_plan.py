@@ -42,6 +42,8 @@ def lib():
     l.dgp2_make_recorded.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                      C.c_double, C.c_char_p, C.c_int]
     l.dgp2_rebuild_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+    l.dgp2_assign_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    l.dgp2_format_with_prio.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     return l
 
 
@@ -331,6 +333,43 @@ def test_tuning_records_round_trip_to_the_same_job_lists(lib):
     lib.dgp2_make_recorded(b, b"B3", n_rows, 256, slots[lvl], lvl, slack, snake, xhead, 0.0, line, 256)
     old = " ".join(line.value.decode().split()[:9]) + "\n"
     assert lib.dgp2_rebuild_matches(b, old.encode(), 0, 256, slots[lvl]) == 1
+    # ... and one without the eleventh (before the wave priorities): priority mode 0
+    ten = " ".join(line.value.decode().split()[:10]) + "\n"
+    assert len(line.value.decode().split()) == 11 and lib.dgp2_rebuild_matches(b, ten.encode(), 0, 256, slots[lvl]) == 1
+    lib.dgp2_free(b)
+    lib.dgp_free(h)
+
+
+def test_wave_priorities_follow_the_predicted_job_length_and_change_nothing_else(lib):
+    """JobDesc::prio (s_setprio of the job's workgroup): 3 for jobs predicted within a quarter of the longest job of the list, 2, 1, 0
+    below; same jobs, same order; recorded as the eleventh field of a tuning record and rebuilt from it; mode 0 clears them."""
+    h, info = build(lib, "deconv_bwd", 4, 4, 8, 8, 256, 128, 256)            # CelebA's 4x4 <- 8x8 backward: 36 .. 100 K chunks per job
+    b = lib.dgp2_build(h)
+    line = C.create_string_buffer(256)
+    n = lib.dgp2_make_recorded(b, b"B2", 1280, 256, 3, 1, 1.04, 0, 0.0, 0.0, line, 256)
+    before = (C.c_int * (6 * n))(); lib.dgp2_jobs(b, before)
+    pr = (C.c_int * n)()
+    lib.dgp2_assign_priorities(b, 256, 3, 1, pr)
+    after = (C.c_int * (6 * n))(); lib.dgp2_jobs(b, after)
+    assert list(before) == list(after)                                        # cls, shape, n0, n_first, j_first, m_valid untouched
+    jobs = np.array(after).reshape(n, 6)
+    cl = (C.c_int * 128)(); lib.dgp2_classes(b, cl)
+    chunks = np.array(cl).reshape(-1, 2)[jobs[:, 0], 1]
+    work = chunks * np.array([128 * 128, 64 * 128, 64 * 64])[jobs[:, 1]]      # MFMA work of the job's tile x K
+    pr = np.array(pr)
+    assert set(pr) <= {0, 1, 2, 3} and pr.max() == 3 and pr.min() < 3
+    assert pr[np.argmax(work)] == 3
+    order = np.argsort(work, kind="stable")
+    assert (np.diff(pr[order]) >= 0).all()                                    # monotone in the job's work
+    # the record carries the mode: rebuilt with it -> the list that is current; without it -> another one (the prio fields differ)
+    with_prio = C.create_string_buffer(256)
+    assert lib.dgp2_format_with_prio(b, line.value, 1, with_prio, 256) == 0
+    assert with_prio.value.decode().split()[10] == "1"
+    assert lib.dgp2_rebuild_matches(b, with_prio.value, 0, 256, 3) == 1
+    assert lib.dgp2_rebuild_matches(b, line.value, 0, 256, 3) == 0
+    pr0 = (C.c_int * n)()
+    lib.dgp2_assign_priorities(b, 256, 3, 0, pr0)
+    assert not np.array(pr0).any() and lib.dgp2_rebuild_matches(b, line.value, 0, 256, 3) == 1
     lib.dgp2_free(b)
     lib.dgp_free(h)
 
@@ -349,6 +388,9 @@ def test_tuning_text_id_ignores_order_and_measured_durations():
     assert tuning_text_id(a10) == tuning_text_id(b10) != tuning_text_id(c10)
     # a nine-field record of a round-4a text is a taper of 0
     assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 293.500\n") == tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0\n")
+    # the eleventh field, the priority mode, names another list; absent = 0
+    assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0\n") == tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 2.0 0\n")
+    assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 1\n") != tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0\n")
 
 
 def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
