@@ -155,8 +155,9 @@ struct dg_handle {
     int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
     int job_taper_tune = 1;        // 1 = tapered lists (dg_plan.h JobModel::taper) are among the timed candidates
     // Wave priorities by predicted job length (dg_types.h JobDesc::prio): 1 = the best lists of the timing are timed again with
-    // priorities and the faster form is kept (default), 0 = never, 2 = every list carries them (measurement, bit-identity tests)
-    int job_prio = 1;
+    // priorities and the faster form is kept, 0 = never (default), 2 = every list carries them (measurement, bit-identity tests)
+    int job_prio = 0;              // (measured, profiles/r05_ab_prio.txt: the arbiter follows the priorities, the launches last the same)
+    int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
     // launch took the same time (465 vs 466 us), fetched the same bytes across the L2/fabric boundary (907 vs 910 MB raw) and
@@ -576,8 +577,15 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 sn.jl.snake = 1;
                 sn.jobs = c.jobs;
                 dg::snake_order(sn.jobs, cus);
+                // third candidate: the jobs partitioned into per-CU sets of equal predicted work (dg_plan.h balance_order)
+                Cand bl;
+                bl.jl = c.jl;
+                bl.jl.snake = 2;
+                bl.jobs = c.jobs;
+                dg::balance_order(op.bplan, bl.jobs, op.family, cus, h->job_slots_per_cu[op.family][lvl], jm);
                 add(std::move(c));
                 add(std::move(sn));
+                if (h->job_balance) add(std::move(bl));
             } else {
                 add(std::move(c));
             }
@@ -695,7 +703,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 for (size_t i = 0; i < cands.size(); ++i)
                     if (cands[i].ms < 1e29f)
                     fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
                             i == best ? "  <- kept" : "");
             }
@@ -1763,7 +1771,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
         k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
-        k == "jobs.taper_tune" || k == "jobs.prio") {
+        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1775,6 +1783,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.xcd_head") h->job_xcd_head = v;
         else if (k == "jobs.taper") h->job_model.taper = v;
         else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
+        else if (k == "jobs.balance") h->job_balance = v != 0.0;
         else if (k == "jobs.prio") h->job_prio = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }

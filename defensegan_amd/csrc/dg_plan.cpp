@@ -321,6 +321,37 @@ void snake_order(std::vector<JobDesc>& jobs, int cus) {
         std::reverse(jobs.begin() + g0, jobs.begin() + std::min(jobs.size(), g0 + (size_t)cus));
 }
 
+void balance_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int cus, int slots_per_cu, const JobModel& model) {
+    const size_t n = jobs.size();
+    if (cus <= 0 || n <= (size_t)cus || n > (size_t)cus * (size_t)slots_per_cu) return;
+    const int slots = cus * slots_per_cu;
+    std::vector<size_t> idx(n);
+    std::vector<double> us(n);
+    for (size_t i = 0; i < n; ++i) { idx[i] = i; us[i] = job_us(p, jobs[i], family, slots, model); }
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return us[a] > us[b]; });
+    // bins 0 .. (n mod cus) - 1 take one job more: every round of `cus` positions but the last is full, so that position
+    // r * cus + b really is bin b's r-th job
+    const size_t lo = n / (size_t)cus, extra = n % (size_t)cus;
+    std::vector<std::vector<size_t>> bin((size_t)cus);
+    std::vector<double> sum((size_t)cus, 0.0);
+    for (size_t k = 0; k < n; ++k) {
+        size_t best = (size_t)cus;
+        for (size_t b = 0; b < (size_t)cus; ++b) {
+            const size_t cap = lo + (b < extra ? 1 : 0);
+            if (bin[b].size() >= cap) continue;
+            if (best == (size_t)cus || sum[b] < sum[best]) best = b;
+        }
+        bin[best].push_back(idx[k]);
+        sum[best] += us[idx[k]];
+    }
+    std::vector<JobDesc> out;
+    out.reserve(n);
+    for (size_t r = 0; r <= lo; ++r)
+        for (size_t b = 0; b < (size_t)cus; ++b)
+            if (r < bin[b].size()) out.push_back(jobs[bin[b][r]]);
+    jobs.swap(out);
+}
+
 void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode) {
     double longest = 0.0;
     for (const JobDesc& j : jobs) longest = std::max(longest, job_us(p, j, family, slots, model));
@@ -377,7 +408,8 @@ std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus,
     m.taper = r.taper;
     std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);
     if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
-    if (r.snake) snake_order(jobs, cus);
+    if (r.snake == 2) balance_order(p, jobs, family, cus, slots_per_cu, m);
+    else if (r.snake) snake_order(jobs, cus);
     if (r.prio) assign_priorities(p, jobs, family, cus * slots_per_cu, m, r.prio);
     return jobs;
 }

@@ -96,7 +96,7 @@ struct TuneRecord {
     int n_rows = 0;
     int min_level = 0;
     double slack = 0.0;        // build_jobs' cutting threshold (<= 0: its ladder, 1e30: never cut)
-    int snake = 0;             // every other round of `cus` jobs reversed
+    int snake = 0;             // 1: every other round of `cus` jobs reversed; 2: balance_order
     int xcd_order = 0;         // order_for_xcd with head fraction xcd_head
     double xcd_head = 0.0;
     int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
@@ -111,6 +111,12 @@ bool parse_tune_record(const char** p, TuneRecord* r);
 std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus, int slots_per_cu, const TuneRecord& r,
                                       const JobModel& model = JobModel(), double* predicted_us = nullptr);
 void snake_order(std::vector<JobDesc>& jobs, int cus);
+// A list that fits the resident slots (jobs <= cus * slots_per_cu) is dispatched in one go, workgroup i to CU ~ i mod cus, and a
+// CU shares its matrix pipes among its resident jobs whatever their sizes: when the launch ends is decided by the CU with the
+// most WORK, not by the longest job.  balance_order partitions the jobs into `cus` bins of equal cardinality (+- 1) and nearly
+// equal predicted work (longest job first into the lightest bin that still has room) and writes bin b's jobs to the positions
+// b, b + cus, b + 2 cus, ...  (TuneRecord::snake = 2).  A pure permutation; lists that do not fit are left alone.
+void balance_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int cus, int slots_per_cu, const JobModel& model);
 // JobDesc::prio by predicted length: a job whose predicted duration (cost model, at the list's residency) is in the top quarter
 // of the longest job's gets priority 3, the next quarter 2, ... ; mode 0 clears them.  Order and arithmetic are untouched.
 void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode);

@@ -483,3 +483,40 @@ def test_every_class_with_taps_is_a_rectangular_grid(lib):
             if k > 0:
                 assert wc >= 1 and s % wc == 0, (kind, p, i, s, wc)
         lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_balance_order_gives_every_cu_the_same_work(lib):
+    """A list that fits the resident slots is dispatched workgroup i -> CU i mod 256 and a CU shares its matrix pipes among its
+    resident jobs: balance_order (TuneRecord.snake = 2) permutes the list so that positions b, b + 256, b + 512, ... -- CU b's jobs --
+    carry nearly the same predicted work for every b (plain longest-first order hands CU 0 the longest job of every round)."""
+    h, info = build(lib, "deconv_bwd", 4, 4, 8, 8, 256, 128, 256)            # CelebA's 4x4 <- 8x8 backward, 1280 rows
+    b = lib.dgp2_build(h)
+    cl = (C.c_int * 128)(); lib.dgp2_classes(b, cl)
+    chunks_of = np.array(cl).reshape(-1, 2)[:, 1]
+    area = np.array([128 * 128, 64 * 128, 64 * 64])
+
+    def per_cu(order_flag):
+        line = C.create_string_buffer(256)
+        n = lib.dgp2_make_recorded(b, b"B2", 1280, 256, 5, 2, 1e30, order_flag, 0.0, 0.0, line, 256)     # everything in quarters: 1280 jobs = 5 per CU
+        assert n == 1280 and lib.dgp2_rebuild_matches(b, line.value, 0, 256, 5) == 1                      # the record rebuilds the order
+        j = (C.c_int * (6 * n))(); lib.dgp2_jobs(b, j)
+        j = np.array(j).reshape(n, 6)
+        work = chunks_of[j[:, 0]] * area[j[:, 1]]
+        key = sorted(map(tuple, j.tolist()))
+        return np.array([work[c::256].sum() for c in range(256)]), key
+    plain, k0 = per_cu(0)
+    snake, k1 = per_cu(1)
+    bal, k2 = per_cu(2)
+    assert k0 == k1 == k2                                                     # permutations of one list
+    spread = lambda w: (w.max() - w.min()) / w.mean()
+    print("per-CU work spread (max - min) / mean: plain %.3f, snake %.3f, balanced %.3f" % (spread(plain), spread(snake), spread(bal)))
+    assert spread(plain) > 0.15 and spread(bal) < 0.06 and spread(bal) <= spread(snake)
+    # a list with more jobs than resident slots is left in its order
+    line = C.create_string_buffer(256)
+    n = lib.dgp2_make_recorded(b, b"B2", 2560, 256, 5, 2, 1e30, 2, 0.0, 0.0, line, 256)
+    j2 = (C.c_int * (6 * n))(); lib.dgp2_jobs(b, j2)
+    n0 = lib.dgp2_make_recorded(b, b"B2", 2560, 256, 5, 2, 1e30, 0, 0.0, 0.0, line, 256)
+    j0 = (C.c_int * (6 * n0))(); lib.dgp2_jobs(b, j0)
+    assert n == n0 > 1280 and list(j2) == list(j0)
+    lib.dgp2_free(b)
+    lib.dgp_free(h)
