@@ -157,6 +157,7 @@ struct dg_handle {
     // Wave priorities by predicted job length (dg_types.h JobDesc::prio): 1 = the best lists of the timing are timed again with
     // priorities and the faster form is kept, 0 = never (default), 2 = every list carries them (measurement, bit-identity tests)
     int job_prio = 0;              // (measured, profiles/r05_ab_prio.txt: the arbiter follows the priorities, the launches last the same)
+    int job_spread = 1;            // 1 = the fastest multi-round lists are also timed in spread order (dg_plan.h spread_order)
     int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
@@ -642,6 +643,27 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             if (level_best[c.jl.min_level] > 1.02f * plain_best) { c.ms = 1e30f; continue; }      // never uploaded, never kept
             ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
         }
+        if (ok && h->job_spread) {
+            // the three fastest multi-round lists so far, once more in spread order (dg_plan.h spread_order: same jobs, desynchronised)
+            std::vector<size_t> top;
+            for (size_t i = 0; i < cands.size(); ++i)
+                if (cands[i].ms < 1e29f && cands[i].jl.snake == 0 && !cands[i].jl.xcd_order &&
+                    cands[i].jobs.size() > (size_t)cus * h->job_slots_per_cu[op.family][cands[i].jl.min_level]) top.push_back(i);
+            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
+            if (top.size() > 3) top.resize(3);
+            for (size_t k = 0; ok && k < top.size(); ++k) {
+                Cand c;
+                c.jl = cands[top[k]].jl;
+                c.jl.d_jobs = nullptr;
+                c.jl.snake = 3;
+                c.jobs = cands[top[k]].jobs;
+                dg::JobModel jm = h->job_model;
+                jm.taper = c.jl.taper;
+                dg::spread_order(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][c.jl.min_level], jm);
+                ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+                cands.push_back(std::move(c));
+            }
+        }
         if (ok && h->job_prio == 1) {
             // the three fastest lists so far, once more with wave priorities by predicted job length (same jobs, same order)
             std::vector<size_t> top;
@@ -703,7 +725,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 for (size_t i = 0; i < cands.size(); ++i)
                     if (cands[i].ms < 1e29f)
                     fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
                             i == best ? "  <- kept" : "");
             }
@@ -1771,7 +1793,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
         k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
-        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance") {
+        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance" || k == "jobs.spread") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1784,6 +1806,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.taper") h->job_model.taper = v;
         else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
         else if (k == "jobs.balance") h->job_balance = v != 0.0;
+        else if (k == "jobs.spread") h->job_spread = v != 0.0;
         else if (k == "jobs.prio") h->job_prio = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
         else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }

@@ -352,6 +352,36 @@ void balance_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family,
     jobs.swap(out);
 }
 
+void spread_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, double frac) {
+    const size_t n = jobs.size();
+    if (n <= (size_t)slots || slots <= 0) return;
+    (void)p; (void)family; (void)model;
+    // groups of equal length = (class, shape); `take` of the first round's slots go to the groups in proportion to their share of
+    // the list (their first jobs), the other slots to the head of the list as before
+    std::map<std::pair<int, int>, size_t> count, taken;
+    for (const JobDesc& j : jobs) ++count[std::make_pair(j.cls, j.shape)];
+    const size_t take = (size_t)(frac * slots);
+    std::map<std::pair<int, int>, size_t> quota;
+    for (const auto& kv : count) quota[kv.first] = (size_t)((double)take * (double)kv.second / (double)n + 0.5);
+    std::vector<char> mixed(n, 0);
+    size_t n_mixed = 0;
+    for (size_t i = 0; i < n && n_mixed < take; ++i) {
+        const auto key = std::make_pair(jobs[i].cls, jobs[i].shape);
+        if (taken[key] < quota[key]) { ++taken[key]; mixed[i] = 1; ++n_mixed; }
+    }
+    // first round = the mixed jobs + the longest-first head of the others, in list (longest-first) order; then the rest
+    std::vector<JobDesc> first, rest;
+    first.reserve((size_t)slots);
+    size_t head_left = (size_t)slots - n_mixed;
+    for (size_t i = 0; i < n; ++i) {
+        if (mixed[i]) first.push_back(jobs[i]);
+        else if (head_left) { first.push_back(jobs[i]); --head_left; }
+        else rest.push_back(jobs[i]);
+    }
+    first.insert(first.end(), rest.begin(), rest.end());
+    jobs.swap(first);
+}
+
 void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode) {
     double longest = 0.0;
     for (const JobDesc& j : jobs) longest = std::max(longest, job_us(p, j, family, slots, model));
@@ -408,7 +438,8 @@ std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus,
     m.taper = r.taper;
     std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);
     if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
-    if (r.snake == 2) balance_order(p, jobs, family, cus, slots_per_cu, m);
+    if (r.snake == 3) spread_order(p, jobs, family, cus * slots_per_cu, m);
+    else if (r.snake == 2) balance_order(p, jobs, family, cus, slots_per_cu, m);
     else if (r.snake) snake_order(jobs, cus);
     if (r.prio) assign_priorities(p, jobs, family, cus * slots_per_cu, m, r.prio);
     return jobs;

@@ -96,7 +96,7 @@ struct TuneRecord {
     int n_rows = 0;
     int min_level = 0;
     double slack = 0.0;        // build_jobs' cutting threshold (<= 0: its ladder, 1e30: never cut)
-    int snake = 0;             // 1: every other round of `cus` jobs reversed; 2: balance_order
+    int snake = 0;             // 1: every other round of `cus` jobs reversed; 2: balance_order; 3: spread_order
     int xcd_order = 0;         // order_for_xcd with head fraction xcd_head
     double xcd_head = 0.0;
     int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
@@ -117,6 +117,13 @@ void snake_order(std::vector<JobDesc>& jobs, int cus);
 // equal predicted work (longest job first into the lightest bin that still has room) and writes bin b's jobs to the positions
 // b, b + cus, b + 2 cus, ...  (TuneRecord::snake = 2).  A pure permutation; lists that do not fit are left alone.
 void balance_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int cus, int slots_per_cu, const JobModel& model);
+// Lists of several dispatch rounds.  In longest-first order the first round is `slots` jobs of ONE length: they end together,
+// their successors start together (all in their start-up and first operand burst at once) and end together again.  spread_order
+// hands `frac` of the first round's slots to ALL lengths of the list in proportion to their counts (a job of duration D only has
+// to start before T - D, and the displaced long jobs start as soon as the first short ones end), the rest of the round and
+// everything behind it stays longest first: jobs then end and start one by one from the first turnover on.  A pure permutation
+// (TuneRecord::snake = 3).
+void spread_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, double frac = 0.5);
 // JobDesc::prio by predicted length: a job whose predicted duration (cost model, at the list's residency) is in the top quarter
 // of the longest job's gets priority 3, the next quarter 2, ... ; mode 0 clears them.  Order and arithmetic are untouched.
 void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model, int mode);

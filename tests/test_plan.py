@@ -520,3 +520,31 @@ def test_balance_order_gives_every_cu_the_same_work(lib):
     assert n == n0 > 1280 and list(j2) == list(j0)
     lib.dgp2_free(b)
     lib.dgp_free(h)
+
+
+def test_spread_order_mixes_lengths_in_the_first_round(lib):
+    """spread_order (TuneRecord.snake = 3) on a list of several dispatch rounds: a permutation; the first round of 768 jobs is no
+    longer ONE length (longest-first order: Generator.3's backward at 2560 rows starts with 768 jobs of 50 chunks, which end
+    together and whose successors start together); half of it still is the head of the list, and everything behind the first
+    round is in its old (longest-first) order."""
+    h, info = build(lib, "deconv_bwd", 7, 7, 14, 14, 128, 64, 128)           # MNIST Generator.3 backward
+    b = lib.dgp2_build(h)
+    cl = (C.c_int * 128)(); lib.dgp2_classes(b, cl)
+    chunks_of = np.array(cl).reshape(-1, 2)[:, 1]
+    area = np.array([128 * 128, 64 * 128, 64 * 64])
+
+    def jobs_of(flag):
+        line = C.create_string_buffer(256)
+        n = lib.dgp2_make_recorded(b, b"B3", 2560, 256, 3, 1, 1e30, flag, 0.0, 0.5, line, 256)
+        assert lib.dgp2_rebuild_matches(b, line.value, 0, 256, 3) == 1
+        j = (C.c_int * (6 * n))(); lib.dgp2_jobs(b, j)
+        return np.array(j).reshape(n, 6)
+    plain, spread = jobs_of(0), jobs_of(3)
+    assert sorted(map(tuple, plain.tolist())) == sorted(map(tuple, spread.tolist()))
+    work = lambda j: chunks_of[j[:, 0]] * area[j[:, 1]]
+    wp, ws = work(plain), work(spread)
+    assert len(np.unique(wp[:768])) == 1 and len(np.unique(ws[:768])) >= 4   # one length -> a mix
+    assert (ws[:768] == ws.max()).sum() >= 384                                # at least half of the round is still the longest jobs
+    assert (np.diff(ws[768:]) <= 0).all()                                     # behind the first round: longest first as before
+    lib.dgp2_free(b)
+    lib.dgp_free(h)
