@@ -82,6 +82,10 @@ struct JobList {
     double predicted_us = 0.0;     // simulated makespan of the cost model
     double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
     dg::JobDesc* d_jobs = nullptr;
+    // K-pair jobs (dg_types.h): arrival counters and accumulator images, in the SAME allocation behind the job records
+    unsigned* d_pair_count = nullptr;
+    float* d_pair = nullptr;
+    size_t pair_count_stride = 0, pair_stride = 0;   // elements per copy: one copy per concurrent row group (option two_streams)
 };
 
 struct GemmOp {
@@ -157,7 +161,8 @@ struct dg_handle {
     // Wave priorities by predicted job length (dg_types.h JobDesc::prio): 1 = the best lists of the timing are timed again with
     // priorities and the faster form is kept, 0 = never (default), 2 = every list carries them (measurement, bit-identity tests)
     int job_prio = 0;              // (measured, profiles/r05_ab_prio.txt: the arbiter follows the priorities, the launches last the same)
-    int job_spread = 1;            // 1 = the fastest multi-round lists are also timed in spread order (dg_plan.h spread_order)
+    int job_spread = 0;            // 1 = the fastest multi-round lists are also timed in spread order (dg_plan.h spread_order); measured
+                                   // slower on every layer (profiles/r05_ab_list_orders.txt): off
     int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
@@ -465,13 +470,15 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
-dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out) {
+dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out, int group = 0) {
     dg::GemmArgs a;
     a.A = A;
     a.W = op.W;
     a.Out = Out;
     a.bias = op.bias;
     a.jobs = jl.d_jobs;
+    a.pair_scratch = jl.d_pair ? jl.d_pair + (size_t)group * jl.pair_stride : nullptr;
+    a.pair_count = jl.d_pair_count ? jl.d_pair_count + (size_t)group * jl.pair_count_stride : nullptr;
     a.cls = op.d_cls;
     a.taps = op.d_btaps;
     a.pos_a = op.d_pos_a;
@@ -490,12 +497,30 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     return a;
 }
 
-bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs) {
+// copies of a list's K-pair scratch: one per row group that may run concurrently (option two_streams)
+int pair_copies(const dg_handle* h) { return h->two_streams > 1 ? std::min(h->two_streams, (int)dg_handle::kMaxGroups) : 1; }
+
+bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs, int family, int copies) {
     jl.n_jobs = (int)jobs.size();
-    if (hipMalloc(&jl.d_jobs, (jobs.size() + 1) * sizeof(dg::JobDesc)) != hipSuccess) return false;
-    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess) {
+    // one allocation: [job records][pair counters x copies][pair accumulator images x copies] (every free of d_jobs frees all of
+    // it).  A copy per row group that may launch this list concurrently on its own stream (two groups of equal size share a list)
+    const dg::PairNeeds pn = dg::pair_needs(jobs, family);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t jobs_bytes = up((jobs.size() + 1) * sizeof(dg::JobDesc));
+    const size_t count_bytes = up((size_t)pn.pairs * sizeof(unsigned));
+    const size_t img_bytes = up((size_t)pn.floats * sizeof(float));
+    if (!pn.pairs) copies = 0;
+    char* base = nullptr;
+    if (hipMalloc(&base, jobs_bytes + (count_bytes + img_bytes) * (size_t)copies) != hipSuccess) return false;
+    jl.d_jobs = reinterpret_cast<dg::JobDesc*>(base);
+    jl.d_pair_count = pn.pairs ? reinterpret_cast<unsigned*>(base + jobs_bytes) : nullptr;
+    jl.d_pair = pn.pairs ? reinterpret_cast<float*>(base + jobs_bytes + count_bytes * (size_t)copies) : nullptr;
+    jl.pair_count_stride = count_bytes / sizeof(unsigned);
+    jl.pair_stride = img_bytes / sizeof(float);
+    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess ||
+        (pn.pairs && hipMemset(jl.d_pair_count, 0, count_bytes * (size_t)copies) != hipSuccess)) {
         (void)hipFree(jl.d_jobs);
-        jl.d_jobs = nullptr;
+        jl.d_jobs = nullptr; jl.d_pair_count = nullptr; jl.d_pair = nullptr;
         return false;
     }
     return true;
@@ -633,7 +658,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         for (size_t i = 0; ok && i < cands.size(); ++i) {
             Cand& c = cands[i];
             if (c.jl.taper > 0.0) continue;
-            ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+            ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
             if (ok && c.ms < level_best[c.jl.min_level]) level_best[c.jl.min_level] = c.ms;
         }
         const float plain_best = std::min(level_best[0], std::min(level_best[1], level_best[2]));
@@ -641,7 +666,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             Cand& c = cands[i];
             if (c.jl.taper <= 0.0) continue;
             if (level_best[c.jl.min_level] > 1.02f * plain_best) { c.ms = 1e30f; continue; }      // never uploaded, never kept
-            ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+            ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
         }
         if (ok && h->job_spread) {
             // the three fastest multi-round lists so far, once more in spread order (dg_plan.h spread_order: same jobs, desynchronised)
@@ -660,7 +685,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 dg::JobModel jm = h->job_model;
                 jm.taper = c.jl.taper;
                 dg::spread_order(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][c.jl.min_level], jm);
-                ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
                 cands.push_back(std::move(c));
             }
         }
@@ -682,7 +707,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 bool any = false;
                 for (const dg::JobDesc& j : c.jobs) any = any || j.prio != 0;
                 if (!any) continue;
-                ok = upload_jobs(c.jl, c.jobs) && time_list(c.jl, 1, &c.ms);
+                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
                 cands.push_back(std::move(c));
             }
         }
@@ -737,7 +762,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         if (e1) (void)hipEventDestroy(e1);
     }
     JobList jl = cands[best].jl;
-    if (!jl.d_jobs && !upload_jobs(jl, cands[best].jobs)) return nullptr;
+    if (!jl.d_jobs && !upload_jobs(jl, cands[best].jobs, op.family, pair_copies(h))) return nullptr;
     if (op.jobs.size() >= 16) {                 // callers with many distinct batch sizes: keep the table bounded
         (void)hipFree(op.jobs.front().d_jobs);
         op.jobs.erase(op.jobs.begin());
@@ -848,7 +873,10 @@ int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, h
     if (lin_stationary(h, op)) return run_lin_stationary(h, op, A, Out, n_rows, s, prof);
     const JobList* jl = find_jobs(op, n_rows);
     if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
-    const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out);
+    int group = 0;                                   // the row group launching: its own copy of the list's pair scratch
+    for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i)
+        if (s == h->side_stream[i] && s != nullptr) group = i + 1;
+    const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out, group);
     char sym[64];
     snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, jl->min_level);
     {
@@ -1652,7 +1680,7 @@ int dg_import_tuning(dg_handle* h, const char* text) {
         if ((int)jobs.size() != r.n_jobs)
             return fail(DG_E_INVALID, "layer %s, %d rows: the record describes %d jobs, this build makes %d (other cost model or planner)",
                         r.op.c_str(), r.n_rows, r.n_jobs, (int)jobs.size());
-        if (!upload_jobs(jl, jobs)) return fail(DG_E_NOMEM, "cannot upload the job list of layer %s", r.op.c_str());
+        if (!upload_jobs(jl, jobs, op->family, pair_copies(h))) return fail(DG_E_NOMEM, "cannot upload the job list of layer %s", r.op.c_str());
         ++h->list_epoch;                 // from here on lists are replaced: a captured loop may point at one (also when a later record fails)
         for (auto it = op->jobs.begin(); it != op->jobs.end();)
             if (it->n_rows == r.n_rows) { (void)hipFree(it->d_jobs); it = op->jobs.erase(it); } else ++it;
@@ -1728,8 +1756,11 @@ int dg_set_option(dg_handle* h, const char* key, const char* value) {
 static int set_option(dg_handle* h, const char* key, const char* value) {
     const std::string k(key);
     if (k == "two_streams") {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
         h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
         if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
+        drop_job_lists(h);                     // a list's K-pair scratch is sized by the number of groups that may launch it at once
         return DG_OK;
     }
     if (k == "lr_schedule") {

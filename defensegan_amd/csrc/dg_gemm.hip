@@ -273,6 +273,51 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         t[0] = tr0; t[1] = wall_clock64(); t[2] = hwid; t[3] = nchunks;
     }
 #endif
+    // ---- K-pair jobs (dg_types.h): this job covered half of the class's taps.  Its raw accumulators go to the pair's scratch
+    // image (write-through stores: the partner may sit on another XCD), every wave drains its stores, barrier, ONE ticket per
+    // workgroup from the pair's counter (the hand-off recipe of the programming guide, guideline 16 / split-K seam).  The first
+    // arriver is done; the second adds the partner's image (sc1 loads: L1 bypassed) to its own accumulators -- a + b = b + a, so
+    // either arrival order gives the same bits -- and runs the epilogue.  Nobody ever waits for anybody.
+    if (jb.pair_id != 0) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int TILE_FLOATS = BM * BN;
+        float* const img = g.pair_scratch + (long long)jb.pair_off;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(img, 0, 0x7ffffff0, 0x00020000);
+        // image layout: [role][wave][i][j][quad of 4 accumulator registers][lane][4] -- every store / load instruction moves one
+        // contiguous KB
+        const unsigned mine = (unsigned)(jb.pair_role * TILE_FLOATS + wave * (TM * TN * 1024)) * 4u + (unsigned)lane * 16u;
+        const unsigned theirs = (unsigned)((1 - jb.pair_role) * TILE_FLOATS + wave * (TM * TN * 1024)) * 4u + (unsigned)lane * 16u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    f32x4 v = {acc[i][j][q4 * 4 + 0], acc[i][j][q4 * 4 + 1], acc[i][j][q4 * 4 + 2], acc[i][j][q4 * 4 + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs, (int)(mine + (unsigned)(((i * TN + j) * 4 + q4) * 1024)), 0, 16);
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* const flag = reinterpret_cast<unsigned*>(smem);          // (both stages are free: every wave is past its last chunk)
+        if (tid == 0) *flag = __builtin_amdgcn_atomic_inc32(g.pair_count + (jb.pair_id - 1), 1u, __ATOMIC_RELAXED, "agent");
+        __syncthreads();
+        const unsigned ticket = __builtin_amdgcn_readfirstlane(*flag);
+        if (ticket == 0) return;                                            // the partner will find this half in the scratch
+        __syncthreads();                                                    // (smem is reused by the epilogue's transposition tiles)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x4 o[4];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    o[q4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(theirs + (unsigned)(((i * TN + j) * 4 + q4) * 1024)), 0, 16));
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][q4 * 4 + e] += o[q4][e];
+            }
+    }
     // ---- epilogue: each 32x32 accumulator tile is transposed through this wave's 4 KB slice of the stage the last chunk
     // did NOT use, so that a lane owns 4 consecutive channels of one row: b128 stores (and b128 gate loads).
     float* tb = reinterpret_cast<float*>(smem + (nchunks & 1) * STAGE_BYTES + wave * 4096);

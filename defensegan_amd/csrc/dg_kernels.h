@@ -65,6 +65,10 @@ struct GemmArgs {
     int mode;                // EpiMode
     int n_jobs;
     int min_level;           // smallest shape code among the jobs (0 = the list holds full tiles)
+    // K-pair jobs (dg_types.h JobDesc::pair_id): accumulator images of the list's pairs and their arrival counters (zero between
+    // launches: the second arrival wraps a counter back to zero); nullptr when the list has no pair
+    float* pair_scratch;
+    unsigned* pair_count;
 #ifdef DG_MEASURE
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 #endif

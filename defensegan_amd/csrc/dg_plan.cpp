@@ -201,8 +201,9 @@ int shape_bn(int family, int shape) { return kShapeBN[family][shape]; }
 
 double job_us(const BatchedPlan& p, const JobDesc& j, int family, int slots, const JobModel& m) {
     // a job occupies its tile's full MFMA footprint whatever m_valid is
-    const double flop = 2.0 * p.cls[j.cls].nchunks * 32.0 * shape_bm(family, j.shape) * shape_bn(family, j.shape);
-    return flop / (m.rate[family][j.shape] * 1e6 / slots) + m.fixed_us[family][j.shape];
+    (void)p;
+    const double flop = 2.0 * j.nchunks * 32.0 * shape_bm(family, j.shape) * shape_bn(family, j.shape);      // the job's own K range
+    return flop / (m.rate[family][j.shape] * 1e6 / slots) + m.fixed_us[family][j.shape] + (j.pair_id ? m.pair_us[j.shape] : 0.0);
 }
 
 // One pass of "longest first with cutting on demand": jobs are handed to the earliest free of `slots` servers in descending
@@ -217,7 +218,14 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
         while (level < max_level && kShapeBM[family][level + 1] >= rows && kShapeBN[family][level + 1] == kShapeBN[family][level]) ++level;
         return level;
     };
+    // (a piece of a paired class stands for BOTH its K-pair jobs: they are cut together -- their shapes must match -- and `us`
+    // is the longer half's cost)
     struct Piece { double us; int cls; int level; long long m0; int rows; int n0; unsigned seq; };
+    const int cpt = p.kch / 32;
+    auto half_taps = [&](int cls, int role) {
+        const int nt = p.cls[(size_t)cls].nchunks / cpt, first = pair_first_taps(p, cls);
+        return role == 0 ? first : nt - first;
+    };
     auto cmp = [](const Piece& a, const Piece& b) { return a.us < b.us || (a.us == b.us && a.seq > b.seq); };
     std::priority_queue<Piece, std::vector<Piece>, decltype(cmp)> pool(cmp);
     unsigned seq = 0;
@@ -225,8 +233,11 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
     auto cost = [&](int cls, int level) {
         JobDesc j = {};
         j.cls = cls; j.shape = level;
+        j.nchunks = p.cls[(size_t)cls].nchunks;
+        if (class_is_paired(p, cls)) { j.pair_id = 1; j.nchunks = half_taps(cls, 1) * cpt; }
         return job_us(p, j, family, slots, model);
     };
+    auto n_jobs_of = [&](int cls) { return class_is_paired(p, cls) ? 2 : 1; };
     for (int c = 0; c < (int)p.cls.size(); ++c) {
         const long long M = (long long)n_rows * p.cls[c].pos_count;
         for (long long m0 = 0; m0 < M; m0 += BM)
@@ -237,7 +248,7 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
                 for (int r0 = 0; r0 < rows; r0 += bm)
                     for (int c0 = 0; c0 < BN; c0 += bn) {
                         Piece pc = {cost(c, level), c, level, m0 + r0, std::min(bm, rows - r0), n0 + c0, seq++};
-                        total += pc.us;
+                        total += pc.us * n_jobs_of(c);
                         pool.push(pc);
                     }
             }
@@ -246,6 +257,8 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
     for (int i = 0; i < slots; ++i) free_at.push(0.0);
     std::vector<JobDesc> out;
+    int n_pairs = 0;
+    long long pair_floats = 0;
     while (!pool.empty()) {
         Piece pc = pool.top();
         pool.pop();
@@ -265,33 +278,58 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
                 }
             continue;
         }
-        free_at.pop();
-        free_at.push(t0 + pc.us);
         const int s = p.cls[pc.cls].pos_count;
-        JobDesc j = {};
-        j.cls = pc.cls;
-        j.shape = pc.level;
-        j.n0 = pc.n0;
-        j.n_first = (int)(pc.m0 / s);
-        j.j_first = (int)(pc.m0 % s);
-        j.m_valid = pc.rows;
         const ClassDesc& cd = p.cls[pc.cls];
-        j.pos_begin = cd.pos_begin;
-        j.pos_count = cd.pos_count;
-        j.tap_begin = cd.tap_begin;
-        j.nchunks = cd.nchunks;
-        j.magic = cd.magic;
-        j.n_taps = cd.nchunks / (p.kch / 32);
-        j.wc = cd.wc; j.wc_magic = cd.wc_magic;
-        j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
-        j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
-        if (cd.nchunks > 0) { j.tap0_a_off = p.taps[cd.tap_begin].a_off; j.tap0_w_off = p.taps[cd.tap_begin].w_off; }
-        out.push_back(j);
+        const bool paired = class_is_paired(p, pc.cls);
+        for (int role = 0; role < (paired ? 2 : 1); ++role) {
+            const double ts = free_at.top();                 // the second half takes the next free slot
+            free_at.pop();
+            free_at.push(ts + pc.us);
+            JobDesc j = {};
+            j.cls = pc.cls;
+            j.shape = pc.level;
+            j.n0 = pc.n0;
+            j.n_first = (int)(pc.m0 / s);
+            j.j_first = (int)(pc.m0 % s);
+            j.m_valid = pc.rows;
+            j.pos_begin = cd.pos_begin;
+            j.pos_count = cd.pos_count;
+            j.magic = cd.magic;
+            j.wc = cd.wc; j.wc_magic = cd.wc_magic;
+            j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
+            j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
+            // the job's own taps: all of the class's, or -- K-pair jobs -- its half
+            const int t0_tap = paired && role == 1 ? pair_first_taps(p, pc.cls) : 0;
+            j.n_taps = paired ? half_taps(pc.cls, role) : cd.nchunks / cpt;
+            j.tap_begin = cd.tap_begin + t0_tap;
+            j.nchunks = j.n_taps * cpt;
+            if (j.nchunks > 0) { j.tap0_a_off = p.taps[(size_t)j.tap_begin].a_off; j.tap0_w_off = p.taps[(size_t)j.tap_begin].w_off; }
+            if (paired) {
+                j.pair_id = n_pairs + 1;
+                j.pair_role = role;
+                j.pair_off = (int)pair_floats;
+            }
+            out.push_back(j);
+        }
+        if (paired) {
+            ++n_pairs;
+            pair_floats += 2LL * shape_bm(family, pc.level) * shape_bn(family, pc.level);
+        }
     }
     return out;
 }
 
 }  // namespace
+
+PairNeeds pair_needs(const std::vector<JobDesc>& jobs, int family) {
+    PairNeeds n;
+    for (const JobDesc& j : jobs) {
+        if (!j.pair_id) continue;
+        n.pairs = std::max(n.pairs, j.pair_id);
+        n.floats = std::max(n.floats, (long long)j.pair_off + 2LL * shape_bm(family, j.shape) * shape_bn(family, j.shape));
+    }
+    return n;
+}
 
 void order_for_xcd(std::vector<JobDesc>& jobs, int n_rows, double head_frac, int n_xcd) {
     if (n_xcd < 2 || n_rows < n_xcd || head_frac <= 0.0) return;

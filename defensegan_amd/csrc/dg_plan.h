@@ -62,12 +62,28 @@ BatchedPlan make_batched(const LayerPlan& p);
 // cut: along N) -- never along K -- whose pieces queue up again, down to 64x64.  slack <= 0 picks, from a fixed ladder,
 // the value with the smallest simulated makespan; slack >= 1e20 never cuts.  min_level > 0 starts every tile cut to that
 // level (1 halves, 2 quarters): such a list needs less LDS and registers per workgroup, so the caller may pass more slots.
+// Classes of at least this many K chunks (with at least two taps) are computed by K-pair jobs (dg_types.h JobDesc::pair_id):
+// 64 = the 16- / 20- / 25-tap classes of the 4x4 <-> 7x7 / 8x8 backward layers (64 / 80 / 100 chunks) and the 9-tap class of
+// their forward layers (72).  A constant of the build: which classes are paired must not depend on the row count or the list.
+constexpr int kPairMinChunks = 64;
+inline bool class_is_paired(const BatchedPlan& p, int cls) {
+    return p.cls[(size_t)cls].nchunks >= kPairMinChunks && p.cls[(size_t)cls].nchunks / (p.kch / 32) >= 2;
+}
+// taps of the first half of a paired class (the second half takes the rest)
+inline int pair_first_taps(const BatchedPlan& p, int cls) { return p.cls[(size_t)cls].nchunks / (p.kch / 32) / 2; }
+// scratch a job list needs: floats of accumulator images, number of pair counters
+struct PairNeeds { long long floats = 0; int pairs = 0; };
+PairNeeds pair_needs(const std::vector<JobDesc>& jobs, int family);
+
 struct JobModel {
     // measured on MI355X at 12 500 rows (profiles/r02_*): TFLOP/s of a chip full of jobs of one shape, by (family, level),
     // at the residency that shape allows (2 / 3 / 5 workgroups per CU), and the prologue + epilogue of one job in
     // microseconds of its slot's time (from the K = 128 Linear layer, where they are a third of a job)
     double rate[2][3] = {{141.5, 138.5, 134.0}, {139.0, 136.5, 131.5}};
     double fixed_us[2][3] = {{7.5, 5.0, 3.4}, {7.5, 5.0, 3.4}};
+    // what a K-pair job adds to its slot's time: its accumulator image written through (64 / 32 / 16 KB: the guide's publish-large
+    // row prices 64 KB at 3 us), the ticket, and for the second arriver the partner's image read back
+    double pair_us[3] = {5.0, 3.5, 2.5};
     // Taper (round 4): real jobs do not run at the model's speed (a workgroup on a CU with fewer neighbours is faster, operands
     // miss or hit), so where the model sees a level end the CUs finish 3-7 % of the launch apart (tools/job_trace.py: mean last-job
     // end 273 of 294 us for Generator.2's backward) -- by about a tenth of the duration of the jobs that were started LAST.  With

@@ -58,7 +58,17 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     // priority by predicted length the long jobs take the pipe first and end early, the short ones -- which have slack -- fill in:
     // completion times spread out instead of piling up at the end of the first dispatch round.  Results cannot change.
     int prio;
-    int pad[9];
+    // K-pair jobs.  A tile of a class with many K chunks (dg_plan.h kPairMinChunks) is ONE dependent chain that lasts as long as
+    // the whole launch when a SIMD is shared three ways; such a tile is computed by TWO jobs, each over half of the class's taps
+    // (tap_begin / n_taps / nchunks / tap0_* above describe the job's own half): both leave their raw accumulators in the launch's
+    // scratch (write-through stores), draw a ticket from the pair's counter, and the one that arrives second adds its partner's
+    // half and runs the epilogue.  out = half0 + half1, each half a k-ordered chain from zero: float addition commutes, so the
+    // result does not depend on which half arrives second, nor on the job list, nor on the batch (the classes that are
+    // paired are a property of the layer plan).
+    int pair_id;         // 0 = not paired; else 1 + the pair's counter index
+    int pair_role;       // 0 / 1: which half of the taps
+    int pair_off;        // float offset of the pair's two accumulator images in the scratch (role r at pair_off + r * rows * columns)
+    int pad[6];
 };
 static_assert(sizeof(JobDesc) == 128, "two 64-byte scalar loads");
 

@@ -1,6 +1,7 @@
 // TEST SUPPORT (never linked into the product library): executes a dg::LayerPlan with plain host
 // loops so the per-position tap tables can be checked against the oracle on a CPU-only box.
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -171,15 +172,26 @@ void dgp2_jobs(void* h, int* out) {           // per job: cls, shape, n0, n_firs
         o[0] = j.cls; o[1] = j.shape; o[2] = j.n0; o[3] = j.n_first; o[4] = j.j_first; o[5] = j.m_valid;
     }
 }
+void dgp2_job_pairs(void* h, int* out) {      // per job: its own K chunks, pair id (0 = not a K-pair job), role, float offset of the pair's images
+    const Batched& b = *static_cast<Batched*>(h);
+    for (size_t i = 0; i < b.jobs.size(); ++i) {
+        const dg::JobDesc& j = b.jobs[i];
+        int* o = out + 4 * i;
+        o[0] = j.nchunks; o[1] = j.pair_id; o[2] = j.pair_role; o[3] = j.pair_off;
+    }
+}
 // Executes the job list the way the device kernel addresses it (row split by the class's magic multiplier, a_off relative
 // to pos_a); `touched` (same shape as Out, int32) counts the writes per output element.
 void dgp2_apply(void* h, const double* A, const double* W, const double* bias, double* Out, int* touched, int mode) {
     const Batched& b = *static_cast<Batched*>(h);
     const dg::BatchedPlan& p = b.plan;
+    // K-pair jobs (dg_types.h JobDesc::pair_id): each covers half of the class's taps; the half that comes first in the list
+    // leaves its sums here, the other adds them and runs the epilogue (on the device: whichever ARRIVES second; a + b = b + a)
+    std::map<long long, double> half;
     for (const dg::JobDesc& jb : b.jobs) {
         const dg::ClassDesc& cd = p.cls[jb.cls];
         const int bn = b.family == 0 ? (jb.shape == 2 ? 64 : 128) : 64;      // columns of the job (dg_plan.cpp kShapeBN)
-        const int n_taps = cd.nchunks / (p.kch / 32);
+        const int n_taps = jb.n_taps;                                          // the job's OWN taps (jb.tap_begin ...)
         for (int r = 0; r < jb.m_valid; ++r) {
             const unsigned jj = (unsigned)(jb.j_first + r);
             const int q = (int)(((unsigned long long)(jj << 1) * cd.magic) >> 32);
@@ -199,12 +211,18 @@ void dgp2_apply(void* h, const double* A, const double* W, const double* bias, d
                 const int col = jb.n0 + c;
                 double acc = 0.0;
                 for (int t = 0; t < n_taps; ++t) {
-                    const dg::TapEntry& te = p.taps[cd.tap_begin + t];
+                    const dg::TapEntry& te = p.taps[jb.tap_begin + t];
                     const double* a = A + n * p.a_rowstride + pa + te.a_off;
                     const double* w = W + te.w_off + (long long)col * p.w_rowstride;
                     for (int k = 0; k < p.kch; ++k) acc += a[k] * w[k];
                 }
                 const long long o = n * p.out_rowstride + po + col;
+                if (jb.pair_id) {
+                    auto it = half.find(o);
+                    if (it == half.end()) { half[o] = acc; continue; }       // first half of this element: nothing is written yet
+                    acc += it->second;
+                    half.erase(it);
+                }
                 if (mode == 1 || mode == 2) acc += bias[col];
                 if (mode == 2) acc = acc > 0 ? acc : 0;
                 if (mode == 3) acc = Out[o] > 0 ? acc : 0;
