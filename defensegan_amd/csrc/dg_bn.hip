@@ -4,7 +4,10 @@
 // An activation buffer is viewed as [rows, C] (rows = latent rows x spatial positions, C = channels, or
 // rows = latent rows, C = 4096 features for BN1).  All kernels are HBM-bound streaming passes:
 //   partial column sums in float64 (<= 1024 row blocks x column groups of 1024) -> finalize (float64) -> apply.
-// Forward keeps xhat for the backward:  da = (scale*rstd) * (dy - mean(dy) - xhat * mean(dy*xhat)).
+// The deconv / Linear GEMM writes the PRE-ACTIVATIONS into their own buffer (BnArgs.xhat); the forward pass reads them twice
+// (statistics, apply) and writes relu(bn(.)) into the activation buffer -- 3 passes, no separate xhat image (round 5; it was 4) --
+// and the backward pass re-forms xhat = (pre - mean) * rstd from them on the fly (the float expression the forward used to
+// store, so nothing changes in the results):  da = (scale*rstd) * (dy - mean(dy) - xhat * mean(dy*xhat)).
 //
 // Layout of the streaming passes (gfx950): a thread owns 4 consecutive channels (b128 loads), the C/4 channel quads of a row
 // sit on adjacent lanes (a wave reads whole 256 B .. 1 KB runs), the remaining lanes of the workgroup take different rows
@@ -25,8 +28,11 @@ static inline long long bn_rows_per_block(long long rows) {
 }
 
 // part[blk][0][c] = sum_r a[r][c];  part[blk][1][c] = sum_r a[r][c] * (b ? b[r][c] : a[r][c])      (rows of block blk)
+// HAS_B: b holds the layer's PRE-ACTIVATIONS and fstats its forward statistics (mean, rstd): the second factor is
+// xhat = (b - mean) * rstd, formed on the fly -- the same float expression the forward pass used to store
 template <bool HAS_B>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ fstats,
                                                          double* __restrict__ part, long long rows, int C,
                                                          long long rows_per_blk) {
     __shared__ double red[8][256];
@@ -43,13 +49,16 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     if (live) {
         const float* pa = a + c;
         const float* pb = HAS_B ? b + c : nullptr;
+        float4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+        if (HAS_B) { mu = *reinterpret_cast<const float4*>(fstats + c); rs = *reinterpret_cast<const float4*>(fstats + C + c); }
+        auto xhat = [&](float4 v) { float4 o; o.x = (v.x - mu.x) * rs.x; o.y = (v.y - mu.y) * rs.y; o.z = (v.z - mu.z) * rs.z; o.w = (v.w - mu.w) * rs.w; return o; };
         long long r = r0 + rl;
         for (; r + 3LL * lanes < r1; r += 4LL * lanes) {   // 4 rows in flight
             float4 v[4], w[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 v[u] = *reinterpret_cast<const float4*>(pa + (r + (long long)u * lanes) * C);
-                if (HAS_B) w[u] = *reinterpret_cast<const float4*>(pb + (r + (long long)u * lanes) * C);
+                if (HAS_B) w[u] = xhat(*reinterpret_cast<const float4*>(pb + (r + (long long)u * lanes) * C));
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         }
         for (; r < r1; r += lanes) {
             const float4 v = *reinterpret_cast<const float4*>(pa + r * C);
-            const float4 w = HAS_B ? *reinterpret_cast<const float4*>(pb + r * C) : v;
+            const float4 w = HAS_B ? xhat(*reinterpret_cast<const float4*>(pb + r * C)) : v;
             s1[0] += (double)v.x; s2[0] += (double)v.x * (double)w.x;
             s1[1] += (double)v.y; s2[1] += (double)v.y * (double)w.y;
             s1[2] += (double)v.z; s2[2] += (double)v.z * (double)w.z;
@@ -131,14 +140,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
 }
 
-// a: pre-activation in, relu(bn(a)) out (when relu) ; xhat out
-__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(float* __restrict__ a, float* __restrict__ xhat,
+// pre: pre-activations in (kept for the backward pass, which re-forms xhat from them); a: relu(bn(pre)) out (when relu)
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(float* __restrict__ a, const float* __restrict__ pre,
                                                            const float* __restrict__ stats, const float* __restrict__ scale,
                                                            const float* __restrict__ offset, long long total, int C, int relu) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     const int c = (int)(i % C);
-    float4 v = *reinterpret_cast<const float4*>(a + i);
+    float4 v = *reinterpret_cast<const float4*>(pre + i);
     const float4 mu = *reinterpret_cast<const float4*>(stats + c);
     const float4 rs = *reinterpret_cast<const float4*>(stats + C + c);
     const float4 g = *reinterpret_cast<const float4*>(scale + c);
@@ -149,20 +158,22 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(float* __restrict__ a
     if (relu) {
         o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
-    *reinterpret_cast<float4*>(xhat + i) = xh;
     *reinterpret_cast<float4*>(a + i) = o;
 }
 
 // dy (already ReluGrad-masked) in, da out (in place)
-__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ dy, const float* __restrict__ xhat,
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(float* __restrict__ dy, const float* __restrict__ pre,
                                                            const float* __restrict__ fstats, const float* __restrict__ bstats,
                                                            const float* __restrict__ scale, long long total, int C) {
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= total) return;
     const int c = (int)(i % C);
     const float4 d = *reinterpret_cast<const float4*>(dy + i);
-    const float4 xh = *reinterpret_cast<const float4*>(xhat + i);
+    const float4 pv = *reinterpret_cast<const float4*>(pre + i);
+    const float4 mu = *reinterpret_cast<const float4*>(fstats + c);
     const float4 rs = *reinterpret_cast<const float4*>(fstats + C + c);
+    float4 xh;
+    xh.x = (pv.x - mu.x) * rs.x; xh.y = (pv.y - mu.y) * rs.y; xh.z = (pv.z - mu.z) * rs.z; xh.w = (pv.w - mu.w) * rs.w;
     const float4 m1 = *reinterpret_cast<const float4*>(bstats + c);
     const float4 m2 = *reinterpret_cast<const float4*>(bstats + C + c);
     const float4 g = *reinterpret_cast<const float4*>(scale + c);
@@ -180,14 +191,14 @@ static void launch_bn_stats(const float* a, const float* b, const BnArgs& args, 
     const long long rpb = bn_rows_per_block(args.rows);
     const int nblk = (int)((args.rows + rpb - 1) / rpb);
     const dim3 grid((unsigned)nblk, (unsigned)((args.C + BN_COLS - 1) / BN_COLS));
-    if (b) hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
-    else hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(256), 0, s, a, b, args.part, (long long)args.rows, args.C, rpb);
+    if (b) hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(256), 0, s, a, b, (const float*)args.fstats, args.part, (long long)args.rows, args.C, rpb);
+    else hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(256), 0, s, a, b, (const float*)nullptr, args.part, (long long)args.rows, args.C, rpb);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((args.C + 15) / 16), dim3(256), 0, s, args.part, nblk, (long long)args.rows,
                        args.C, stats, forward);
 }
 
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s) {
-    launch_bn_stats(a.a, nullptr, a, a.fstats, 1, s);
+    launch_bn_stats(a.xhat, nullptr, a, a.fstats, 1, s);          // statistics of the pre-activations the GEMM left in a.xhat
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);

@@ -878,7 +878,7 @@ int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, h
         if (s == h->side_stream[i] && s != nullptr) group = i + 1;
     const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out, group);
     char sym[64];
-    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d>", op.family, op.mode, jl->min_level);
+    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d, %s>", op.family, op.mode, jl->min_level, a.pair_scratch ? "true" : "false");
     {
         ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
         dg::launch_gemm(op.family, a, s);
@@ -990,7 +990,10 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     const int n_rows = g.n_rows;
     hipStream_t s = g.s;
     const int64_t r0 = g.row0;
-    int rc = run_gemm(h, h->F1, h->z + r0 * h->latent, h->act[0] + r0 * h->act_row[0], n_rows, s, prof);
+    // a layer with Batchnorm behind it leaves its pre-activations in the layer's own buffer (ActInfo::xhat): the BN pass writes
+    // the activation
+    auto out_of = [&](int d) { return (h->ai[d].has_bn ? h->ai[d].xhat : h->act[d]) + r0 * h->act_row[d]; };
+    int rc = run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
     if (rc) return rc;
     if (h->ai[0].has_bn) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
@@ -998,7 +1001,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     }
     const int nd = (int)h->dec.size();
     for (int d = 0; d + 1 < nd; ++d) {
-        rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], h->act[d + 1] + r0 * h->act_row[d + 1], n_rows, s, prof);
+        rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], out_of(d + 1), n_rows, s, prof);
         if (rc) return rc;
         if (h->ai[d + 1].has_bn) {
             ProfScope ps(h, s, prof, "BNf", 0.0);

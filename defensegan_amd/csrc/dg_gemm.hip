@@ -39,7 +39,7 @@ __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 constexpr int SG_MFMA = 0x8, SG_VMEM = 0x10, SG_DSREAD = 0x100;
 
 // (FAM, TAG only make every call site its own specialization: hipcc's host pass rejects a second reference to one)
-template <int TM, int TN, int WM, int WN, int MODE, int FAM, int TAG>
+template <int TM, int TN, int WM, int WN, int MODE, int FAM, int TAG, bool PAIR>
 __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, char* smem) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;   // waves are WM x WN, each owns TM x TN 32x32 accumulator tiles
@@ -278,7 +278,9 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     // workgroup from the pair's counter (the hand-off recipe of the programming guide, guideline 16 / split-K seam).  The first
     // arriver is done; the second adds the partner's image (sc1 loads: L1 bypassed) to its own accumulators -- a + b = b + a, so
     // either arrival order gives the same bits -- and runs the epilogue.  Nobody ever waits for anybody.
-    if (jb.pair_id != 0) {
+    // (compiled only into the PAIR instantiations, which run the lists that hold such jobs: with this block present hipcc allocates
+    // and schedules the main loop of EVERY instantiation differently -- Generator.3's forward, which has no pair, lost 1 % to it)
+    if constexpr (PAIR) if (jb.pair_id != 0) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         constexpr int TILE_FLOATS = BM * BN;
         float* const img = g.pair_scratch + (long long)jb.pair_off;
@@ -350,7 +352,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
 // FAM 1: 64-column layers: 256x64 (waves 4 x 1: every wave reads the same 64 filter rows) / 128x64 / 64x64.
 // MINLEVEL = the smallest shape code in the launch's job list: a list without full tiles needs less LDS and fewer
 // registers, so more workgroups are resident per CU (launches too small to fill the chip with big tiles).
-template <int FAM, int MODE, int MINLEVEL>
+template <int FAM, int MODE, int MINLEVEL, bool PAIR>
 __global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (MINLEVEL == 1 ? 3 : 4)) void gemm_batched_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const JobDesc jb = g.jobs[blockIdx.x];
@@ -365,31 +367,38 @@ __global__ __launch_bounds__(256, MINLEVEL == 0 ? 2 : (MINLEVEL == 1 ? 3 : 4)) v
     }
     if constexpr (FAM == 0) {
         if constexpr (MINLEVEL <= 0) {
-            if (shape == 0) { run_job<2, 2, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 0) { run_job<2, 2, 2, 2, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem); return; }
         }
         if constexpr (MINLEVEL <= 1) {
-            if (shape == 1) { run_job<1, 2, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 1) { run_job<1, 2, 2, 2, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem); return; }
         }
-        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem);
+        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem);
     } else {
         if constexpr (MINLEVEL <= 0) {
-            if (shape == 0) { run_job<2, 2, 4, 1, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 0) { run_job<2, 2, 4, 1, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem); return; }
         }
         if constexpr (MINLEVEL <= 1) {
-            if (shape == 1) { run_job<2, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem); return; }
+            if (shape == 1) { run_job<2, 1, 2, 2, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem); return; }
         }
-        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL>(g, jb, smem);
+        run_job<1, 1, 2, 2, MODE, FAM, MINLEVEL, PAIR>(g, jb, smem);
     }
 }
 
-template <int FAM, int MODE, int MINLEVEL>
-void launch_fml(const GemmArgs& a, hipStream_t s) {
+template <int FAM, int MODE, int MINLEVEL, bool PAIR>
+void launch_fmlp(const GemmArgs& a, hipStream_t s) {
     const int lds = gemm_lds_bytes(FAM, MINLEVEL);
     static PerDeviceOnce attr;
     if (attr.need(lds))
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE, MINLEVEL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
+}
+
+// a list with K-pair jobs (its scratch is set) runs the PAIR instantiation, every other list the plain one
+template <int FAM, int MODE, int MINLEVEL>
+void launch_fml(const GemmArgs& a, hipStream_t s) {
+    if (a.pair_scratch) launch_fmlp<FAM, MODE, MINLEVEL, true>(a, s);
+    else launch_fmlp<FAM, MODE, MINLEVEL, false>(a, s);
 }
 
 template <int FAM, int MODE>

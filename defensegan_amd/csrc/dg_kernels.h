@@ -188,8 +188,9 @@ void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, in
 // An activation buffer viewed as [rows, C] (rows = latent rows x positions); per-column mean / biased variance,
 // eps 1e-5, statistics reduced in float64.
 struct BnArgs {
-    float* a;            // fwd: pre-activation in, [relu](bn(a)) out | bwd: masked dy in, da out (in place)
-    float* xhat;         // [rows, C] normalised activations (written by fwd, read by bwd)
+    float* a;            // fwd: [relu](bn(pre)) out | bwd: masked dy in, da out (in place)
+    float* xhat;         // [rows, C] the layer's PRE-ACTIVATIONS (written by the GEMM, read by fwd and bwd; xhat = (pre - mean) * rstd
+                         // is re-formed from them where it is needed)
     double* part;        // [nblk <= bn_max_blocks(), 2, C] scratch
     float* fstats;       // [2, C] mean, rstd (written by fwd)
     float* bstats;       // [2, C] mean(dy), mean(dy*xhat) (written by bwd)

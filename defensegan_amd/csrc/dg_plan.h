@@ -63,9 +63,11 @@ BatchedPlan make_batched(const LayerPlan& p);
 // the value with the smallest simulated makespan; slack >= 1e20 never cuts.  min_level > 0 starts every tile cut to that
 // level (1 halves, 2 quarters): such a list needs less LDS and registers per workgroup, so the caller may pass more slots.
 // Classes of at least this many K chunks (with at least two taps) are computed by K-pair jobs (dg_types.h JobDesc::pair_id):
-// 64 = the 16- / 20- / 25-tap classes of the 4x4 <-> 7x7 / 8x8 backward layers (64 / 80 / 100 chunks) and the 9-tap class of
-// their forward layers (72).  A constant of the build: which classes are paired must not depend on the row count or the list.
-constexpr int kPairMinChunks = 64;
+// 80 = the 20- / 25-tap classes of the 4x4 <-> 7x7 / 8x8 backward layers (80 / 100 chunks).  Measured with 64 (which also pairs
+// their 16-tap class and the 9-tap class, 72 chunks, of the forward layers): the forward layers lose 1-2 % to it, the backward
+// layers gain 3 % (MNIST, 2560 rows) / 8 % (CelebA, 1280 rows) -- profiles/r05_ab_k_pair.txt.  A constant of the build: which
+// classes are paired must not depend on the row count or the list.
+constexpr int kPairMinChunks = 80;
 inline bool class_is_paired(const BatchedPlan& p, int cls) {
     return p.cls[(size_t)cls].nchunks >= kPairMinChunks && p.cls[(size_t)cls].nchunks / (p.kch / 32) >= 2;
 }

@@ -34,7 +34,8 @@ BN = [[128, 128, 64], [64, 64, 64]]
 def _lib():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
     srcs = [os.path.join(SUP, "plan_host_exec.cpp"), os.path.join(CSRC, "dg_plan.cpp")]
-    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+    deps = srcs + [os.path.join(CSRC, "dg_plan.h"), os.path.join(CSRC, "dg_types.h")]
+    if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-I", CSRC, "-o", SO] + srcs)
     l = C.CDLL(SO)
     l.dgp_build.restype = C.c_void_p
