@@ -83,8 +83,9 @@ def traffic_for(workload, layers, B, R, tuning_id=None):
     return int(sum(vals) / len(vals)), "profiles/" + TRAFFIC_FILE
 
 
-TRAFFIC_FILE = "r04_pmc_traffic.json"
-TUNING_FILE = "r04_tuning_%s.txt"       # profiles/: the job-list choice of the profiling run, per architecture
+PROFILE_ROUND = "r05"                  # profiles/<round>_*: the evidence collected on this build (tools/final_validation.sh)
+TRAFFIC_FILE = PROFILE_ROUND + "_pmc_traffic.json"
+TUNING_FILE = PROFILE_ROUND + "_tuning_%s.txt"       # profiles/: the job-list choice of the profiling run, per architecture
 
 
 def make_inputs(gan, a, B, rank=0, first_image=0):
@@ -316,7 +317,7 @@ def main():
     ap.add_argument("--images", type=int, default=10000, help="--strong: images in the evaluated list")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
     ap.add_argument("--retune", action="store_true",
-                    help="time the job lists on this box instead of installing the committed choice (profiles/r04_tuning_<arch>.txt)")
+                    help="time the job lists on this box instead of installing the committed choice (profiles/r05_tuning_<arch>.txt)")
     ap.add_argument("--use_bn", action="store_true",
                     help="USE_BN: True variant of the generator (batch-statistics Batchnorm after every hidden layer, "
                          "tflib/ops/batchnorm.py:80-93); not a BASELINE config (the shipped cfgs have USE_BN: False)")
