@@ -66,7 +66,9 @@ BatchedPlan make_batched(const LayerPlan& p);
 // 80 = the 20- / 25-tap classes of the 4x4 <-> 7x7 / 8x8 backward layers (80 / 100 chunks).  Measured with 64 (which also pairs
 // their 16-tap class and the 9-tap class, 72 chunks, of the forward layers): the forward layers lose 1-2 % to it, the backward
 // layers gain 3 % (MNIST, 2560 rows) / 8 % (CelebA, 1280 rows) -- profiles/r05_ab_k_pair.txt.  A constant of the build: which
-// classes are paired must not depend on the row count or the list.
+// classes are paired must not depend on the row count or the list.  (Also measured and dropped: pairing the 50-chunk, few-position
+// classes of the 7x7 <- 14x14 / 8x8 <- 16x16 backward layers as well: Generator.3's backward 315 -> 324.5 us on MNIST, 230 -> 232.6
+// on CelebA -- pairs only pay where one chain lasts most of the launch.)
 constexpr int kPairMinChunks = 80;
 inline bool class_is_paired(const BatchedPlan& p, int cls) {
     return p.cls[(size_t)cls].nchunks >= kPairMinChunks && p.cls[(size_t)cls].nchunks / (p.kch / 32) >= 2;
