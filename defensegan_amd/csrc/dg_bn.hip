@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // backward: stats[0][c] = mean(dy), stats[1][c] = mean(dy * xhat)
 // 16 channels per workgroup, 16 threads per channel: thread j of a channel adds blocks j, j+16, ... (4 loads in flight), the
 // 16 sums are folded in LDS in a fixed order.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int nblk, long long rows, int C,
+template <typename PartT>          // double: bn_partial_kernel's sums; float: the GEMM epilogue's per-32-row-block sums (EPI_BIAS_STATS)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const PartT* __restrict__ part, int nblk, long long rows, int C,
                                                           float* __restrict__ stats, int forward) {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
@@ -113,15 +114,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
             double x1[4], x2[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                x1[u] = part[((long long)(k + u * BN_FSPLIT) * 2 + 0) * C + c];
-                x2[u] = part[((long long)(k + u * BN_FSPLIT) * 2 + 1) * C + c];
+                x1[u] = (double)part[((long long)(k + u * BN_FSPLIT) * 2 + 0) * C + c];
+                x2[u] = (double)part[((long long)(k + u * BN_FSPLIT) * 2 + 1) * C + c];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s1 += x1[u]; s2 += x2[u]; }
         }
         for (; k < nblk; k += BN_FSPLIT) {
-            s1 += part[((long long)k * 2 + 0) * C + c];
-            s2 += part[((long long)k * 2 + 1) * C + c];
+            s1 += (double)part[((long long)k * 2 + 0) * C + c];
+            s2 += (double)part[((long long)k * 2 + 1) * C + c];
         }
     }
     red[0][tid] = s1; red[1][tid] = s2;
@@ -193,12 +194,19 @@ static void launch_bn_stats(const float* a, const float* b, const BnArgs& args, 
     const dim3 grid((unsigned)nblk, (unsigned)((args.C + BN_COLS - 1) / BN_COLS));
     if (b) hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(256), 0, s, a, b, (const float*)args.fstats, args.part, (long long)args.rows, args.C, rpb);
     else hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(256), 0, s, a, b, (const float*)nullptr, args.part, (long long)args.rows, args.C, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((args.C + 15) / 16), dim3(256), 0, s, args.part, nblk, (long long)args.rows,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((args.C + 15) / 16), dim3(256), 0, s, (const double*)args.part, nblk, (long long)args.rows,
                        args.C, stats, forward);
 }
 
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s) {
     launch_bn_stats(a.xhat, nullptr, a, a.fstats, 1, s);          // statistics of the pre-activations the GEMM left in a.xhat
+    const long long total = (long long)a.rows * a.C;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
+                       a.scale, a.offset, total, a.C, relu);
+}
+
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((a.C + 15) / 16), dim3(256), 0, s, block_sums, nblk, (long long)a.rows, a.C, a.fstats, 1);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);

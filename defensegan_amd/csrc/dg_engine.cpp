@@ -68,6 +68,7 @@ struct ActInfo {
     float* offset = nullptr;  // [bn_C]
     float* fstats = nullptr;  // [2, bn_C]
     float* bstats = nullptr;  // [2, bn_C]
+    float* block_sums = nullptr;  // [blocks][2][bn_C]: per-32-row-block column sums left by the producing GEMM's epilogue (EPI_BIAS_STATS)
 };
 
 // Job list of a position-batched launch (dg_gemm.hip), one per row count a layer has been run with.
@@ -100,6 +101,7 @@ struct GemmOp {
     int mode = 0;
     const float* W = nullptr;
     const float* bias = nullptr;
+    float* stats = nullptr;   // EPI_BIAS_STATS: the block sums of the activation this layer produces (ActInfo::block_sums)
 };
 
 constexpr int kJobTraceCap = 65536;
@@ -163,6 +165,9 @@ struct dg_handle {
     int job_prio = 0;              // (measured, profiles/r05_ab_prio.txt: the arbiter follows the priorities, the launches last the same)
     int job_spread = 0;            // 1 = the fastest multi-round lists are also timed in spread order (dg_plan.h spread_order); measured
                                    // slower on every layer (profiles/r05_ab_list_orders.txt): off
+    // Batchnorm forward statistics from the producing GEMM's epilogue (per-32-row-block column sums, EPI_BIAS_STATS) instead of a
+    // pass over the pre-activations; 0 = the separate pass (cross-check)
+    int bn_fused = 1;
     int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
@@ -371,7 +376,7 @@ int build_plans(dg_handle* h) {
     {
         GemmOp& op = h->F1;
         op.name = "F1";
-        op.mode = h->use_bn ? dg::EPI_BIAS : dg::EPI_BIAS_RELU;
+        op.mode = h->use_bn ? (h->bn_fused ? dg::EPI_BIAS_STATS : dg::EPI_BIAS) : dg::EPI_BIAS_RELU;
         int rc = upload_batched(op, dg::plan_linear_fwd(h->latent, h->lin_out, h->lin_out));
         if (rc) return rc;
     }
@@ -394,7 +399,7 @@ int build_plans(dg_handle* h) {
         {
             GemmOp& op = h->Fd[d];
             op.name = std::string("F") + s.name[10];     // "Generator.N" -> "FN"
-            op.mode = out.has_bn ? dg::EPI_BIAS : (s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS);
+            op.mode = out.has_bn ? (h->bn_fused ? dg::EPI_BIAS_STATS : dg::EPI_BIAS) : (s.act == 0 ? dg::EPI_BIAS_RELU : dg::EPI_BIAS);
             // with BN every stored position is computed (statistics need the cropped row/column too)
             int rc = upload_batched(op, dg::plan_deconv_fwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch,
                                                             s.cin, s.cout, s.cout));
@@ -421,7 +426,7 @@ void free_workspace(dg_handle* h) {
     h->xbuf_floats = 0;
     ++h->list_epoch;                 // captured loops point into these buffers
     for (auto& a : h->act) fr(a);
-    for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); }
+    for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); fr(a.block_sums); }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
     if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
     h->cap_rows = 0;
@@ -461,11 +466,16 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         a.buf = h->act[d];
         if (a.has_bn) {
             HIP_TRY(hipMalloc(&a.xhat, cap * a.row_floats * sizeof(float)));
+            // blocks: ceil(rows * positions_of_class / 32) summed over the classes <= rows * positions / 32 + one per class
+            const size_t blocks = (size_t)(cap * a.bn_rows / 32 + 128);
+            HIP_TRY(hipMalloc(&a.block_sums, blocks * 2 * (size_t)a.bn_C * sizeof(float)));
             const size_t need = (size_t)dg::bn_max_blocks() * 2 * a.bn_C;
             if (need > part_doubles) part_doubles = need;
         }
     }
     if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
+    h->F1.stats = h->ai[0].block_sums;
+    for (int d = 0; d + 1 < nd; ++d) h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums;
     h->cap_rows = cap;
     return DG_OK;
 }
@@ -488,6 +498,8 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.w_rowstride = op.bplan.w_rowstride;
     a.kch = op.bplan.kch;
     a.mode = op.mode;
+    a.stats = op.stats;
+    a.stats_cols = op.bplan.ncols;
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
 #ifdef DG_MEASURE
@@ -995,18 +1007,19 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     auto out_of = [&](int d) { return (h->ai[d].has_bn ? h->ai[d].xhat : h->act[d]) + r0 * h->act_row[d]; };
     int rc = run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
     if (rc) return rc;
-    if (h->ai[0].has_bn) {
+    auto bn_forward = [&](int d, const GemmOp& producer) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
-        dg::launch_bn_forward(bn_args(h, h->ai[0], n_rows), 1, s);
-    }
+        if (producer.mode == dg::EPI_BIAS_STATS)
+            dg::launch_bn_forward_from_blocks(bn_args(h, h->ai[d], n_rows), h->ai[d].block_sums, (int)dg::stat_blocks(producer.bplan, n_rows), 1, s);
+        else
+            dg::launch_bn_forward(bn_args(h, h->ai[d], n_rows), 1, s);
+    };
+    if (h->ai[0].has_bn) bn_forward(0, h->F1);
     const int nd = (int)h->dec.size();
     for (int d = 0; d + 1 < nd; ++d) {
         rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], out_of(d + 1), n_rows, s, prof);
         if (rc) return rc;
-        if (h->ai[d + 1].has_bn) {
-            ProfScope ps(h, s, prof, "BNf", 0.0);
-            dg::launch_bn_forward(bn_args(h, h->ai[d + 1], n_rows), 1, s);
-        }
+        if (h->ai[d + 1].has_bn) bn_forward(d + 1, h->Fd[d]);
     }
     const DeconvSpec& last = h->dec[nd - 1];
     if (h->arch == DG_ARCH_MNIST28) {
@@ -1120,9 +1133,11 @@ int rebuild_plans(dg_handle* h) {
     if (rc) return rc;
     const size_t ndec = h->dec.size();
     h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
+    h->F1.stats = h->ai.empty() ? nullptr : h->ai[0].block_sums;
     h->B1.W = h->lin_w;
     for (size_t d = 0; d + 1 < ndec; ++d) {
         h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
+        h->Fd[d].stats = h->ai[d + 1].block_sums;
         h->Bd[d].W = h->Ft[d];
     }
     return DG_OK;
@@ -1790,6 +1805,13 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         HIP_TRY(hipDeviceSynchronize());
         h->update_fold = atoi(value) != 0;
         return DG_OK;
+    }
+    if (k == "bn_fused") {               // 1 = Batchnorm forward statistics from the GEMM epilogue (default), 0 = a separate pass
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->bn_fused = atoi(value) != 0;
+        drop_job_lists(h);
+        return rebuild_plans(h);
     }
     if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel
         HIP_TRY(hipSetDevice(h->device));

@@ -327,9 +327,10 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     for (int j = 0; j < TN; ++j) {
         const int col = wn * (BN / WN) + j * 32 + ec;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
+        if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU || MODE == EPI_BIAS_STATS) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};     // EPI_BIAS_STATS: this lane's rows of the 32-row block
 #pragma unroll
             for (int e = 0; e < 16; ++e) tb[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + frow] = acc[i][j][e];
 #pragma unroll
@@ -343,6 +344,28 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                     v[q] = t;
                 }
                 if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
+                if constexpr (MODE == EPI_BIAS_STATS) {
+                    if (ovalid[i][p]) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { s1[q] += v[q]; s2[q] = __builtin_fmaf(v[q], v[q], s2[q]); }
+                    }
+                }
+            }
+            if constexpr (MODE == EPI_BIAS_STATS) {
+                // the 8 lanes that share this lane's 4 columns hold the other rows of the 32-row block (er = lane >> 3): a fixed
+                // xor tree over lane bits 3..5, the same for every job shape -- a block's sums do not depend on the job list
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) { s1[q] += __shfl_xor(s1[q], m, 64); s2[q] += __shfl_xor(s2[q], m, 64); }
+                }
+                const int row0 = wm * (BM / WM) + i * 32;                     // first row of this wave's 32-row block inside the job
+                if (er == 0 && row0 < m_valid) {
+                    const long long blk = (long long)jb.stat_base + ((jb.n_first * s_cnt + jb.j_first + row0) >> 5);
+                    float* sp = g.stats + (blk * 2) * g.stats_cols + jb.n0 + col;
+                    *reinterpret_cast<f32x4*>(sp) = s1;
+                    *reinterpret_cast<f32x4*>(sp + g.stats_cols) = s2;
+                }
             }
         }
     }
@@ -414,6 +437,7 @@ void launch_f(const GemmArgs& a, hipStream_t s) {
         case EPI_STORE: launch_fm<FAM, EPI_STORE>(a, s); break;
         case EPI_BIAS: launch_fm<FAM, EPI_BIAS>(a, s); break;
         case EPI_BIAS_RELU: launch_fm<FAM, EPI_BIAS_RELU>(a, s); break;
+        case EPI_BIAS_STATS: launch_fm<FAM, EPI_BIAS_STATS>(a, s); break;
         default: launch_fm<FAM, EPI_MASK>(a, s); break;
     }
 }

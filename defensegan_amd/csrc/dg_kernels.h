@@ -39,6 +39,8 @@ enum EpiMode : int {
     EPI_BIAS = 1,        // out = acc + bias[col]
     EPI_BIAS_RELU = 2,   // out = max(acc + bias[col], 0)          (BiasAdd + Relu)
     EPI_MASK = 3,        // out = out_old > 0 ? acc : 0            (ReluGrad, in place over the activation)
+    EPI_BIAS_STATS = 4,  // out = acc + bias[col], and per 32-row block of the class's M axis the column sums of out and out^2
+                         // (GemmArgs::stats): the Batchnorm forward statistics without a pass over the pre-activations
 };
 
 // ---- position-batched gathered implicit GEMM (dg_gemm.hip) --------------------------------------
@@ -69,6 +71,10 @@ struct GemmArgs {
     // launches: the second arrival wraps a counter back to zero); nullptr when the list has no pair
     float* pair_scratch;
     unsigned* pair_count;
+    // EPI_BIAS_STATS: [blocks][2][stats_cols] floats; block = JobDesc::stat_base + (row of the class's M axis) / 32 -- a fixed
+    // partition of the layer's rows whatever the job list looks like, every block summed in a fixed order: deterministic
+    float* stats;
+    int stats_cols;          // output columns per position (the Batchnorm channels)
 #ifdef DG_MEASURE
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 #endif
@@ -201,6 +207,9 @@ struct BnArgs {
 };
 int bn_max_blocks();        // row blocks of the partial sums, upper bound: part holds bn_max_blocks() * 2 * C doubles
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
+// the forward pass when the GEMM epilogue (EPI_BIAS_STATS) has left per-block column sums in `block_sums` [nblk][2][C] (float):
+// finalize (float64) + apply -- no pass over the pre-activations for the statistics
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s);
 void launch_bn_backward(const BnArgs& a, hipStream_t s);
 
 }  // namespace dg

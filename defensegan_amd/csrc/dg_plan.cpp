@@ -259,6 +259,11 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
     std::vector<JobDesc> out;
     int n_pairs = 0;
     long long pair_floats = 0;
+    std::vector<int> stat_base(p.cls.size(), 0);
+    {
+        long long at = 0;
+        for (size_t c = 0; c < p.cls.size(); ++c) { stat_base[c] = (int)at; at += ((long long)n_rows * p.cls[c].pos_count + 31) / 32; }
+    }
     while (!pool.empty()) {
         Piece pc = pool.top();
         pool.pop();
@@ -295,6 +300,7 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
             j.pos_begin = cd.pos_begin;
             j.pos_count = cd.pos_count;
             j.magic = cd.magic;
+            j.stat_base = stat_base[(size_t)pc.cls];
             j.wc = cd.wc; j.wc_magic = cd.wc_magic;
             j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
             j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
@@ -320,6 +326,12 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
 }
 
 }  // namespace
+
+long long stat_blocks(const BatchedPlan& p, int n_rows) {
+    long long at = 0;
+    for (const ClassDesc& c : p.cls) at += ((long long)n_rows * c.pos_count + 31) / 32;
+    return at;
+}
 
 PairNeeds pair_needs(const std::vector<JobDesc>& jobs, int family) {
     PairNeeds n;

@@ -78,6 +78,8 @@ inline int pair_first_taps(const BatchedPlan& p, int cls) { return p.cls[(size_t
 // scratch a job list needs: floats of accumulator images, number of pair counters
 struct PairNeeds { long long floats = 0; int pairs = 0; };
 PairNeeds pair_needs(const std::vector<JobDesc>& jobs, int family);
+// 32-row statistics blocks of a layer at n_rows latent rows (JobDesc::stat_base): sum over the classes of ceil(n_rows * s_c / 32)
+long long stat_blocks(const BatchedPlan& p, int n_rows);
 
 struct JobModel {
     // measured on MI355X at 12 500 rows (profiles/r02_*): TFLOP/s of a chip full of jobs of one shape, by (family, level),

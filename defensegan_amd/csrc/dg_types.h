@@ -68,7 +68,8 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     int pair_id;         // 0 = not paired; else 1 + the pair's counter index
     int pair_role;       // 0 / 1: which half of the taps
     int pair_off;        // float offset of the pair's two accumulator images in the scratch (role r at pair_off + r * rows * columns)
-    int pad[6];
+    int stat_base;       // EPI_BIAS_STATS: index of the class's first 32-row statistics block (classes in order, ceil(M_c / 32) blocks each)
+    int pad[5];
 };
 static_assert(sizeof(JobDesc) == 128, "two 64-byte scalar loads");
 
