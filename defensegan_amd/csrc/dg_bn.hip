@@ -205,8 +205,51 @@ void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s) {
                        a.scale, a.offset, total, a.C, relu);
 }
 
+// part[range][k][c] (double) = sum over the blocks of the range of sums[blk][k][c] (float), k = 0, 1: the GEMM epilogue's
+// per-32-row-block sums (thousands of blocks for a 14x14 map) folded to at most BN_FOLD_RANGES float64 partials, coalesced over
+// the channels, before the per-channel finalize (which has C / 16 workgroups only)
+constexpr int BN_FOLD_RANGES = 256;
+__global__ __launch_bounds__(256) void bn_fold_blocks_kernel(const float* __restrict__ sums, double* __restrict__ part, int nblk, int C,
+                                                            int blocks_per_range) {
+    // thread = one float4 of the [2][C] record of a block; the 2C/4 quads of a record sit on adjacent lanes, the other lanes of
+    // the workgroup take other blocks of the range
+    const int quads = (2 * C) / 4;
+    const int per = quads < 256 ? quads : 256;             // quads this workgroup covers (2C <= 1024 floats: one pass; BN1's 8192: grid.y)
+    const int lanes = 256 / per;
+    const int tid = threadIdx.x;
+    const int q = blockIdx.y * per + tid % per, bl = tid / per;
+    const int b0 = blockIdx.x * blocks_per_range;
+    const int b1 = b0 + blocks_per_range < nblk ? b0 + blocks_per_range : nblk;
+    __shared__ double red[4][256];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (q < quads && bl < lanes) {
+        for (int b = b0 + bl; b < b1; b += lanes) {
+            const float4 v = *reinterpret_cast<const float4*>(sums + (long long)b * 2 * C + 4 * q);
+            acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+        }
+    }
+    if (lanes > 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[e][tid] = acc[e];
+        __syncthreads();
+        if (bl == 0 && q < quads)
+            for (int k = 1; k < lanes; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += red[e][k * per + tid % per];
+    }
+    if (bl == 0 && q < quads) {
+        double* o = part + (long long)blockIdx.x * 2 * C + 4 * q;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[e];
+    }
+}
+
 void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s) {
-    hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((a.C + 15) / 16), dim3(256), 0, s, block_sums, nblk, (long long)a.rows, a.C, a.fstats, 1);
+    const int per_range = (nblk + BN_FOLD_RANGES - 1) / BN_FOLD_RANGES;
+    const int ranges = (nblk + per_range - 1) / per_range;
+    const int quads = (2 * a.C) / 4;
+    hipLaunchKernelGGL(bn_fold_blocks_kernel, dim3((unsigned)ranges, (unsigned)((quads + 255) / 256)), dim3(256), 0, s, block_sums, a.part, nblk, a.C, per_range);
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);

@@ -147,8 +147,8 @@ def test_bn_statistics_from_the_gemm_epilogue(arch, B, R):
         return gan.loss_grad(x, z)
     y1, l1, d1 = run({})
     y0, l0, d0 = run({"bn_fused": 0})
-    np.testing.assert_allclose(y1, y0, rtol=0, atol=2e-6)
-    np.testing.assert_allclose(l1, l0, rtol=2e-6)
+    np.testing.assert_allclose(y1, y0, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5)
     err = np.abs(d1 - d0).max(axis=1) / np.abs(d0).max()
     assert np.median(err) < 1e-5 and (err < 1e-4).mean() >= 0.95, np.sort(err)[-3:]       # (a ReLU gate at rounding distance may move a row)
     for opts in ({"jobs.min_level": 1, "jobs.tune": 0}, {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.slack": 0.01, "jobs.min_level": 0}):
