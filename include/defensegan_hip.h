@@ -164,6 +164,14 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "jobs.xcd_head"    fraction (default 0 = off; measured, no gain) of a list that is ALSO offered to the timing in XCD-locality order: every
  *                      XCD gets the jobs of one contiguous range of latent rows, all tap classes of a row range next to each other
  *                      in time, so that their shared input rows stay in that XCD's L2 (a permutation of the list)
+ *   "jobs.balance"     1 (default): a list that fits the resident slots is also offered to the timing as per-CU sets of equal
+ *                      predicted work (dg_plan.h balance_order; +0.75 % at the reference's 500 rows, profiles/r05_ab_list_orders.txt)
+ *   "jobs.prio"        wave priorities by predicted job length (s_setprio per job): 0 (default) never, 1 the fastest lists are timed
+ *                      again with them, 2 always.  Measured: the launches last the same (profiles/r05_ab_prio.txt)
+ *   "jobs.spread"      1: the first dispatch round of a multi-round list mixes all job lengths (dg_plan.h spread_order).  Default 0:
+ *                      slower on every layer (profiles/r05_ab_list_orders.txt)
+ *   "bn_fused"         1 (default): with use_bn the Batchnorm forward statistics are per-32-row-block column sums taken in the producing
+ *                      GEMM's epilogue; 0: a separate pass over the pre-activations (float64 sums from the first add)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
  *   "lr_schedule"      "constant" (default): lr == rec_lr at every step, which is what the reference executes -- the step variable
  *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,
@@ -192,7 +200,9 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  * library refuses them): "tail_fwd16" = 0 (32x32x2 CelebA forward tail), "tail_bwd_persist" = 0 + "tail_bwd_bands" (per-band
  * backward tail), "tail_trace", "tail_dbg", "tail_prio", "job_trace" (in-kernel phase traces and phase-removal switches, tools/)
  * Every job-list / launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py): GEMM tiles are only
- * ever cut along M and N, never along K; "nsplit" and "tail_fwd16" change a summation order (agreement to rounding).
+ * ever cut along M and N; along K only the classes of >= 80 K chunks, and those ALWAYS, in two fixed halves whose sums are added
+ * once (K-pair jobs, dg_plan.h kPairMinChunks: a + b = b + a, so the arrival order does not show); "nsplit", "tail_fwd16" and
+ * "bn_fused" change a summation order (agreement to rounding).
  */
 int dg_set_option(dg_handle* h, const char* key, const char* value);
 

@@ -16,6 +16,7 @@ python bench.py --workload celeba --steps 5 --warmup 2 > $O/bench_celeba.json 2>
 python bench.py --workload fmnist --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_fmnist.json 2>> $O/b.err
 python bench.py --strong --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_strong.json 2>> $O/b.err
 python bench.py --batch 50 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_b50.json 2>> $O/b.err
+python bench.py --strong --batch 50 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_strong_b50.json 2>> $O/b.err     # the reference's BATCH_SIZE through the coalescing harness
 python bench.py --use_bn --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_mnist_use_bn.json 2>> $O/b.err
 python bench.py --workload celeba --use_bn --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_celeba_use_bn.json 2>> $O/b.err
 python bench.py --gpus 2 --steps 1 --warmup 0 > $O/bench_gpus2.out 2> $O/bench_gpus2.err; echo "bench.py --gpus 2 on this box: exit status $?" | tee $O/bench_gpus2.status; tail -1 $O/bench_gpus2.err
