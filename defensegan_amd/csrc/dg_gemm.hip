@@ -283,7 +283,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     if constexpr (PAIR) if (jb.pair_id != 0) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         constexpr int TILE_FLOATS = BM * BN;
-        float* const img = g.pair_scratch + (long long)jb.pair_off;
+        float* const img = g.pair_scratch + (long long)jb.pair_off * 256;
         const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(img, 0, 0x7ffffff0, 0x00020000);
         // image layout: [role][wave][i][j][quad of 4 accumulator registers][lane][4] -- every store / load instruction moves one
         // contiguous KB

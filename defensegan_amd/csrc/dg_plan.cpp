@@ -313,7 +313,7 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
             if (paired) {
                 j.pair_id = n_pairs + 1;
                 j.pair_role = role;
-                j.pair_off = (int)pair_floats;
+                j.pair_off = (int)(pair_floats / 256);
             }
             out.push_back(j);
         }
@@ -338,7 +338,7 @@ PairNeeds pair_needs(const std::vector<JobDesc>& jobs, int family) {
     for (const JobDesc& j : jobs) {
         if (!j.pair_id) continue;
         n.pairs = std::max(n.pairs, j.pair_id);
-        n.floats = std::max(n.floats, (long long)j.pair_off + 2LL * shape_bm(family, j.shape) * shape_bn(family, j.shape));
+        n.floats = std::max(n.floats, 256LL * j.pair_off + 2LL * shape_bm(family, j.shape) * shape_bn(family, j.shape));
     }
     return n;
 }

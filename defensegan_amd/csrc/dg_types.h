@@ -67,7 +67,8 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
     // paired are a property of the layer plan).
     int pair_id;         // 0 = not paired; else 1 + the pair's counter index
     int pair_role;       // 0 / 1: which half of the taps
-    int pair_off;        // float offset of the pair's two accumulator images in the scratch (role r at pair_off + r * rows * columns)
+    int pair_off;        // offset of the pair's two accumulator images in the scratch, in units of 256 floats (images are multiples of
+                         // 4096 floats; a float offset would pass 2^31 at ~800 000 latent rows): role r at 256 * pair_off + r * rows * columns
     int stat_base;       // EPI_BIAS_STATS: index of the class's first 32-row statistics block (classes in order, ceil(M_c / 32) blocks each)
     int pad[5];
 };

@@ -582,7 +582,7 @@ def test_k_pair_jobs_split_the_taps_of_the_long_classes_in_two(lib):
         assert pr[a, 1] == pr[c, 1] and (pr[a, 2], pr[c, 2]) == (0, 1) and pr[a, 3] == pr[c, 3]
         taps = class_chunks[a] // 4                                                  # kch = 128: 4 chunks per tap
         assert pr[a, 0] == (taps // 2) * 4 and pr[a, 0] + pr[c, 0] == class_chunks[a]
-        spans.append((pr[a, 3], pr[a, 3] + 2 * area[jobs[a, 1]]))
+        spans.append((256 * pr[a, 3], 256 * pr[a, 3] + 2 * area[jobs[a, 1]]))     # pair_off is in units of 256 floats
     spans.sort()
     assert all(e0 <= s1 for (_, e0), (s1, _) in zip(spans, spans[1:]))               # the pairs' images do not overlap
     assert sorted(set(pr[paired, 1])) == list(range(1, len(idx) // 2 + 1))           # counters 0 .. pairs - 1
