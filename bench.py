@@ -136,9 +136,14 @@ def physical_cores_one_socket():
         return None, ncpu
 
 
+# steps of a thread-count probe: 2-step probes preferred 64 threads on a box where the full-L run is twice as fast on 32 (their
+# three passes are dominated by the thread pool's start-up, not by the convolutions)
+PROBE_STEPS = 6
+
+
 def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
     """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed here) on this box's host
-    cores.  Thread count: the best of {8, 16, 32, 64, physical cores of one socket} on 2-step probes, each probe the FASTEST of
+    cores.  Thread count: the best of {8, 16, 32, 64, physical cores of one socket} on 6-step probes, each probe the FASTEST of
     three repeats (round 4 probed once per count and saw 2.6 ... 5.3 images/s for the same batch on three boxes of one CPU
     model: a single noisy probe picked the count).  Then TWO batches of 16 images run the FULL L steps at that count -- measured,
     not a short sample scaled by (2L-1) -- `value` is the faster one, `spread` = (slower - faster) / faster, both times are in
@@ -156,7 +161,7 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
         probe = None
         for _ in range(3):
             t0 = time.perf_counter()
-            T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
+            T.reconstruct(params, x_np[:nimg], z0, R, PROBE_STEPS, arch=arch, gen=gen)
             dtp = time.perf_counter() - t0
             probe = dtp if probe is None else min(probe, dtp)
             if dtp > 10:
@@ -167,7 +172,7 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
             break
     probe, threads = best
     torch.set_num_threads(threads)
-    per_pass = probe / 3.0                       # 2 steps = 3 passes over nimg images
+    per_pass = probe / (2.0 * PROBE_STEPS - 1.0)   # L steps = 2L - 1 passes over nimg images
     Ls, n_run = L, nimg
     while n_run > 4 and per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
         n_run //= 2
@@ -180,7 +185,7 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
         times.append(time.perf_counter() - t0)
     dt = min(times)
     t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # == dt when the full L ran
-    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads (best of 2-step probes, 3 repeats each) of %d host CPUs (%s physical cores on socket 0), two batches %.1f s and %.1f s, the faster one reported%s" % (
+    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads (best of 6-step probes, 3 repeats each) of %d host CPUs (%s physical cores on socket 0), two batches %.1f s and %.1f s, the faster one reported%s" % (
         n_run, R, Ls, threads, ncpu, phys if phys else "?", times[0], times[1], "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
     return {"value": n_run / t_full, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": ncpu,
             "physical_cores_socket0": phys, "spread": round((max(times) - dt) / dt, 4),

@@ -44,6 +44,7 @@ def _lib():
     l.dgp2_build.argtypes = [C.c_void_p]
     l.dgp2_classes.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp2_jobs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_job_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     l.dgp2_make_recorded.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                      C.c_double, C.c_char_p, C.c_int]
     return l
@@ -65,16 +66,16 @@ def load(path):
     jobs = (C.c_int * (6 * n))()
     l.dgp2_jobs(h2, jobs)
     jobs = np.array(jobs).reshape(n, 6)
-    cl = (C.c_int * 128)()
-    l.dgp2_classes(h2, cl)
-    chunks_of = np.array(cl).reshape(-1, 2)[:, 1]
+    own = (C.c_int * (4 * n))()
+    l.dgp2_job_pairs(h2, own)                      # a job's OWN K chunks (K-pair jobs cover half of their class's taps), pair id, role
+    own = np.array(own).reshape(n, 4)
     blk = d["block"]
     t0 = d["start"].min()
     hw = d["hwid"]
     cu = (blk % 8) * 256 + (((hw >> 8) & 15) | (((hw >> 13) & 7) << 4))
     J = jobs[blk]
-    assert (chunks_of[J[:, 0]] == d["chunks"]).all(), "the rebuilt list is not the traced one"
-    return dict(arch=arch, op=op, rows=rows, fam=0 if p[-1] % 128 == 0 else 1, lvl=lvl, rec=rec, shape=J[:, 1], chunks=d["chunks"],
+    assert (own[blk, 0] == d["chunks"]).all(), "the rebuilt list is not the traced one"
+    return dict(arch=arch, op=op, rows=rows, fam=0 if p[-1] % 128 == 0 else 1, lvl=lvl, rec=rec, shape=J[:, 1], chunks=d["chunks"], paired=own[blk, 1] != 0,
                 s=(d["start"] - t0) / 100.0, e=(d["end"] - t0) / 100.0, cu=cu)
 
 
@@ -85,8 +86,8 @@ def report(path):
     flop = 2.0 * ch * 32 * np.array([BM[fam][q] * BN[fam][q] for q in shape])
     mf = np.array([BM[fam][q] * BN[fam][q] // 256 for q in shape])           # MFMAs per wave and K chunk
     span = e.max()
-    print("== %s %s, %d rows: list '%s' (%d resident per CU), %d jobs, span %.1f us under the trace, %.1f TFLOP/s over the span" % (
-        T["arch"], T["op"], T["rows"], T["rec"], SLOTS[T["lvl"]], len(s), span, flop.sum() / span / 1e6))
+    print("== %s %s, %d rows: list '%s' (%d resident per CU), %d jobs (%d of them K-pair halves), span %.1f us under the trace, %.1f TFLOP/s over the span" % (
+        T["arch"], T["op"], T["rows"], T["rec"], SLOTS[T["lvl"]], len(s), int(T["paired"].sum()), span, flop.sum() / span / 1e6))
     for c in np.unique(ch)[::-1]:
         for q in np.unique(shape):
             for nm, m in (("first round", (ch == c) & (shape == q) & (s < 5)), ("later      ", (ch == c) & (shape == q) & (s >= 5))):
