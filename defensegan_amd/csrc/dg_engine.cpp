@@ -629,6 +629,20 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             }
         }
     }
+    // lists BUILT for one dispatch round with the work balanced over the CUs (dg_plan.h jobs_balanced), one per starting level
+    if (tune && h->job_balance >= 1) {
+        for (int lvl = 0; lvl < n_levels; ++lvl) {
+            if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
+            Cand c;
+            c.jl.n_rows = n_rows;
+            c.jl.min_level = lvl;
+            c.jl.snake = 4;
+            c.jobs = dg::jobs_balanced(op.bplan, n_rows, op.family, cus, h->job_slots_per_cu[op.family][lvl], lvl, h->job_model);
+            if (c.jobs.empty()) continue;
+            c.jl.predicted_us = dg::simulate_jobs(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], h->job_model);
+            cands.push_back(std::move(c));
+        }
+    }
     if (cands.empty()) return nullptr;
     size_t best = 0;
     for (size_t i = 1; i < cands.size(); ++i)
@@ -762,7 +776,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 for (size_t i = 0; i < cands.size(); ++i)
                     if (cands[i].ms < 1e29f)
                     fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 4 ? " built" : cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
                             i == best ? "  <- kept" : "");
             }

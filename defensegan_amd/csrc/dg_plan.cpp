@@ -206,6 +206,62 @@ double job_us(const BatchedPlan& p, const JobDesc& j, int family, int slots, con
     return flop / (m.rate[family][j.shape] * 1e6 / slots) + m.fixed_us[family][j.shape] + (j.pair_id ? m.pair_us[j.shape] : 0.0);
 }
 
+// Turns pieces (class, level, M range, column) into job records: one job, or -- classes of K-pair jobs -- the two half-K jobs, next to
+// each other; hands out the pairs' counters and scratch images and the classes' statistics blocks.
+struct JobEmitter {
+    const BatchedPlan& p;
+    int family;
+    int cpt;
+    int n_pairs = 0;
+    long long pair_floats = 0;
+    std::vector<int> stat_base;
+    JobEmitter(const BatchedPlan& plan, int n_rows, int fam) : p(plan), family(fam), cpt(plan.kch / 32), stat_base(plan.cls.size(), 0) {
+        long long at = 0;
+        for (size_t c = 0; c < p.cls.size(); ++c) { stat_base[c] = (int)at; at += ((long long)n_rows * p.cls[c].pos_count + 31) / 32; }
+    }
+    int half_taps(int cls, int role) const {
+        const int nt = p.cls[(size_t)cls].nchunks / cpt, first = pair_first_taps(p, cls);
+        return role == 0 ? first : nt - first;
+    }
+    void emit(std::vector<JobDesc>& out, int cls, int level, long long m0, int rows, int n0) {
+        const ClassDesc& cd = p.cls[(size_t)cls];
+        const int s = cd.pos_count;
+        const bool paired = class_is_paired(p, cls);
+        for (int role = 0; role < (paired ? 2 : 1); ++role) {
+            JobDesc j = {};
+            j.cls = cls;
+            j.shape = level;
+            j.n0 = n0;
+            j.n_first = (int)(m0 / s);
+            j.j_first = (int)(m0 % s);
+            j.m_valid = rows;
+            j.pos_begin = cd.pos_begin;
+            j.pos_count = cd.pos_count;
+            j.magic = cd.magic;
+            j.stat_base = stat_base[(size_t)cls];
+            j.wc = cd.wc; j.wc_magic = cd.wc_magic;
+            j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
+            j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
+            // the job's own taps: all of the class's, or -- K-pair jobs -- its half
+            const int t0_tap = paired && role == 1 ? pair_first_taps(p, cls) : 0;
+            j.n_taps = paired ? half_taps(cls, role) : cd.nchunks / cpt;
+            j.tap_begin = cd.tap_begin + t0_tap;
+            j.nchunks = j.n_taps * cpt;
+            if (j.nchunks > 0) { j.tap0_a_off = p.taps[(size_t)j.tap_begin].a_off; j.tap0_w_off = p.taps[(size_t)j.tap_begin].w_off; }
+            if (paired) {
+                j.pair_id = n_pairs + 1;
+                j.pair_role = role;
+                j.pair_off = (int)(pair_floats / 256);
+            }
+            out.push_back(j);
+        }
+        if (paired) {
+            ++n_pairs;
+            pair_floats += 2LL * shape_bm(family, level) * shape_bn(family, level);
+        }
+    }
+};
+
 // One pass of "longest first with cutting on demand": jobs are handed to the earliest free of `slots` servers in descending
 // cost; a job that would end after `target` is cut in two along M (then along N) and its pieces go back into the pool, so
 // the launch starts with whole tiles and ends with small ones.  The order of assignment is the dispatch order.
@@ -257,13 +313,7 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
     std::priority_queue<double, std::vector<double>, std::greater<double>> free_at;
     for (int i = 0; i < slots; ++i) free_at.push(0.0);
     std::vector<JobDesc> out;
-    int n_pairs = 0;
-    long long pair_floats = 0;
-    std::vector<int> stat_base(p.cls.size(), 0);
-    {
-        long long at = 0;
-        for (size_t c = 0; c < p.cls.size(); ++c) { stat_base[c] = (int)at; at += ((long long)n_rows * p.cls[c].pos_count + 31) / 32; }
-    }
+    JobEmitter em(p, n_rows, family);
     while (!pool.empty()) {
         Piece pc = pool.top();
         pool.pop();
@@ -283,49 +333,139 @@ std::vector<JobDesc> jobs_for_target(const BatchedPlan& p, int n_rows, int famil
                 }
             continue;
         }
-        const int s = p.cls[pc.cls].pos_count;
-        const ClassDesc& cd = p.cls[pc.cls];
-        const bool paired = class_is_paired(p, pc.cls);
-        for (int role = 0; role < (paired ? 2 : 1); ++role) {
-            const double ts = free_at.top();                 // the second half takes the next free slot
+        for (int role = 0; role < n_jobs_of(pc.cls); ++role) {
+            const double ts = free_at.top();                 // the second half of a K-pair takes the next free slot
             free_at.pop();
             free_at.push(ts + pc.us);
-            JobDesc j = {};
-            j.cls = pc.cls;
-            j.shape = pc.level;
-            j.n0 = pc.n0;
-            j.n_first = (int)(pc.m0 / s);
-            j.j_first = (int)(pc.m0 % s);
-            j.m_valid = pc.rows;
-            j.pos_begin = cd.pos_begin;
-            j.pos_count = cd.pos_count;
-            j.magic = cd.magic;
-            j.stat_base = stat_base[(size_t)pc.cls];
-            j.wc = cd.wc; j.wc_magic = cd.wc_magic;
-            j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
-            j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
-            // the job's own taps: all of the class's, or -- K-pair jobs -- its half
-            const int t0_tap = paired && role == 1 ? pair_first_taps(p, pc.cls) : 0;
-            j.n_taps = paired ? half_taps(pc.cls, role) : cd.nchunks / cpt;
-            j.tap_begin = cd.tap_begin + t0_tap;
-            j.nchunks = j.n_taps * cpt;
-            if (j.nchunks > 0) { j.tap0_a_off = p.taps[(size_t)j.tap_begin].a_off; j.tap0_w_off = p.taps[(size_t)j.tap_begin].w_off; }
-            if (paired) {
-                j.pair_id = n_pairs + 1;
-                j.pair_role = role;
-                j.pair_off = (int)(pair_floats / 256);
-            }
-            out.push_back(j);
         }
-        if (paired) {
-            ++n_pairs;
-            pair_floats += 2LL * shape_bm(family, pc.level) * shape_bn(family, pc.level);
-        }
+        em.emit(out, pc.cls, pc.level, pc.m0, pc.rows, pc.n0);
     }
     return out;
 }
 
 }  // namespace
+
+std::vector<JobDesc> jobs_balanced(const BatchedPlan& p, int n_rows, int family, int cus, int slots_per_cu, int min_level,
+                                   const JobModel& model, double tol) {
+    const int BM = kShapeBM[family][0], BN = kShapeBN[family][0];
+    const int max_level = 2;
+    if (min_level > max_level) min_level = max_level;
+    const int slots = cus * slots_per_cu;
+    struct Piece { double us; int cls; int level; long long m0; int rows; int n0; int njobs; };
+    const int cpt = p.kch / 32;
+    auto cost = [&](int cls, int level) {
+        JobDesc j = {};
+        j.cls = cls; j.shape = level;
+        j.nchunks = p.cls[(size_t)cls].nchunks;
+        if (class_is_paired(p, cls)) { j.pair_id = 1; j.nchunks = (p.cls[(size_t)cls].nchunks / cpt - pair_first_taps(p, cls)) * cpt; }
+        return job_us(p, j, family, slots, model);
+    };
+    std::vector<Piece> pieces;
+    long long n_jobs = 0;
+    for (int c = 0; c < (int)p.cls.size(); ++c) {
+        const long long M = (long long)n_rows * p.cls[c].pos_count;
+        const int nj = class_is_paired(p, c) ? 2 : 1;
+        for (long long m0 = 0; m0 < M; m0 += BM)
+            for (int n0 = 0; n0 < p.ncols; n0 += BN) {
+                const int rows = (int)std::min<long long>(BM, M - m0);
+                int level = min_level;
+                while (level < max_level && kShapeBM[family][level + 1] >= rows && kShapeBN[family][level + 1] == kShapeBN[family][level]) ++level;
+                const int bm = shape_bm(family, level), bn = shape_bn(family, level);
+                for (int r0 = 0; r0 < rows; r0 += bm)
+                    for (int c0 = 0; c0 < BN; c0 += bn) {
+                        pieces.push_back(Piece{cost(c, level) * nj, c, level, m0 + r0, std::min(bm, rows - r0), n0 + c0, nj});
+                        n_jobs += nj;
+                    }
+            }
+    }
+    if (n_jobs > slots || pieces.size() <= (size_t)cus) return {};
+    std::vector<std::vector<size_t>> bin;
+    std::vector<double> load;
+    std::vector<int> count;
+    auto assign = [&]() -> bool {
+        std::vector<size_t> idx(pieces.size());
+        for (size_t i = 0; i < idx.size(); ++i) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return pieces[a].us > pieces[b].us; });
+        bin.assign((size_t)cus, {});
+        load.assign((size_t)cus, 0.0);
+        count.assign((size_t)cus, 0);
+        for (size_t i : idx) {
+            int best = -1;
+            for (int b = 0; b < cus; ++b)
+                if (count[(size_t)b] + pieces[i].njobs <= slots_per_cu && (best < 0 || load[(size_t)b] < load[(size_t)best])) best = b;
+            if (best < 0) return false;
+            bin[(size_t)best].push_back(i);
+            load[(size_t)best] += pieces[i].us;
+            count[(size_t)best] += pieces[i].njobs;
+        }
+        return true;
+    };
+    if (!assign()) return {};
+    for (int iter = 0; iter < 4096; ++iter) {
+        double total = 0.0;
+        int heavy = 0;
+        for (int b = 0; b < cus; ++b) { total += load[(size_t)b]; if (load[(size_t)b] > load[(size_t)heavy]) heavy = b; }
+        if (load[(size_t)heavy] <= (1.0 + tol) * total / cus) break;
+        // the largest piece of the heaviest CU that can still be cut -- if the list has room for one more piece
+        size_t pick = pieces.size();
+        for (size_t i : bin[(size_t)heavy])
+            if (pieces[i].level < max_level && (pick == pieces.size() || pieces[i].us > pieces[pick].us)) pick = i;
+        if (pick == pieces.size() || n_jobs + pieces[pick].njobs > slots) break;
+        const Piece pc = pieces[pick];
+        const int nl = pc.level + 1;
+        const int bm = shape_bm(family, nl), bn = shape_bn(family, nl), cols = shape_bn(family, pc.level);
+        std::vector<Piece> parts;
+        for (int r0 = 0; r0 < pc.rows; r0 += bm)
+            for (int c0 = 0; c0 < cols; c0 += bn)
+                parts.push_back(Piece{cost(pc.cls, nl) * pc.njobs, pc.cls, nl, pc.m0 + r0, std::min(bm, pc.rows - r0), pc.n0 + c0, pc.njobs});
+        if (parts.size() < 2) {                      // a ragged piece that the next level holds whole: just relabel it
+            load[(size_t)heavy] += parts[0].us - pc.us;
+            pieces[pick] = parts[0];
+            continue;
+        }
+        // the first part stays, the others move to the lightest CUs that have a slot -- if that lowers the heaviest load
+        bool moved = false;
+        std::vector<std::pair<size_t, int>> placed;                       // (piece index, bin)
+        double heavy_load = load[(size_t)heavy] - pc.us + parts[0].us;
+        bool ok = true;
+        std::vector<double> load_try = load;
+        std::vector<int> count_try = count;
+        load_try[(size_t)heavy] = heavy_load;
+        for (size_t k = 1; k < parts.size() && ok; ++k) {
+            int best = -1;
+            for (int b = 0; b < cus; ++b)
+                if (b != heavy && count_try[(size_t)b] + pc.njobs <= slots_per_cu && (best < 0 || load_try[(size_t)b] < load_try[(size_t)best])) best = b;
+            if (best < 0 || load_try[(size_t)best] + parts[k].us >= load[(size_t)heavy]) { ok = false; break; }
+            load_try[(size_t)best] += parts[k].us;
+            count_try[(size_t)best] += pc.njobs;
+            placed.push_back(std::make_pair(k, best));
+            moved = true;
+        }
+        if (!ok || !moved) break;                    // no CU can take a part without becoming the heaviest itself: done
+        pieces[pick] = parts[0];
+        for (const auto& pl : placed) {
+            pieces.push_back(parts[pl.first]);
+            bin[(size_t)pl.second].push_back(pieces.size() - 1);
+        }
+        load = load_try;
+        count = count_try;
+        n_jobs += (long long)placed.size() * pc.njobs;
+    }
+    // dispatch order: CU b's jobs at positions b, b + cus, ...; the CUs with the most jobs first, so that every round is a prefix
+    std::vector<int> order((size_t)cus);
+    for (int b = 0; b < cus; ++b) order[(size_t)b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return count[(size_t)a] > count[(size_t)b]; });
+    JobEmitter em(p, n_rows, family);
+    std::vector<std::vector<JobDesc>> per((size_t)cus);
+    for (int b = 0; b < cus; ++b)
+        for (size_t i : bin[(size_t)order[(size_t)b]])
+            em.emit(per[(size_t)b], pieces[i].cls, pieces[i].level, pieces[i].m0, pieces[i].rows, pieces[i].n0);
+    std::vector<JobDesc> out;
+    for (int r = 0; r < slots_per_cu; ++r)
+        for (int b = 0; b < cus; ++b)
+            if ((size_t)r < per[(size_t)b].size()) out.push_back(per[(size_t)b][(size_t)r]);
+    return out;
+}
 
 long long stat_blocks(const BatchedPlan& p, int n_rows) {
     long long at = 0;
@@ -486,6 +626,11 @@ std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus,
                                       const JobModel& model, double* predicted_us) {
     JobModel m = model;
     m.taper = r.taper;
+    if (r.snake == 4) {                          // a work-balanced single-round list is built, not ordered
+        std::vector<JobDesc> jb = jobs_balanced(p, r.n_rows, family, cus, slots_per_cu, r.min_level, m);
+        if (predicted_us) *predicted_us = simulate_jobs(p, jb, family, cus * slots_per_cu, m);
+        return jb;
+    }
     std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);
     if (r.xcd_order) order_for_xcd(jobs, r.n_rows, r.xcd_head);
     if (r.snake == 3) spread_order(p, jobs, family, cus * slots_per_cu, m);

@@ -118,7 +118,7 @@ struct TuneRecord {
     int n_rows = 0;
     int min_level = 0;
     double slack = 0.0;        // build_jobs' cutting threshold (<= 0: its ladder, 1e30: never cut)
-    int snake = 0;             // 1: every other round of `cus` jobs reversed; 2: balance_order; 3: spread_order
+    int snake = 0;             // 1: every other round of `cus` jobs reversed; 2: balance_order; 3: spread_order; 4: jobs_balanced (a list of its own)
     int xcd_order = 0;         // order_for_xcd with head fraction xcd_head
     double xcd_head = 0.0;
     int n_jobs = 0;            // length of the list (checked on import: another planner / cost model makes another list)
@@ -139,6 +139,13 @@ void snake_order(std::vector<JobDesc>& jobs, int cus);
 // equal predicted work (longest job first into the lightest bin that still has room) and writes bin b's jobs to the positions
 // b, b + cus, b + 2 cus, ...  (TuneRecord::snake = 2).  A pure permutation; lists that do not fit are left alone.
 void balance_order(const BatchedPlan& p, std::vector<JobDesc>& jobs, int family, int cus, int slots_per_cu, const JobModel& model);
+// A list BUILT for one dispatch round (TuneRecord::snake = 4): every job resident from the start, so a CU is done when its own
+// jobs' work is done, whatever their lengths.  Tiles start at `min_level`; longest piece first into the lightest CU that still has a
+// slot; while the heaviest CU carries more than (1 + tol) x the mean, its largest piece is cut in two (along M, then N -- never
+// K) and everything is placed again -- as long as the list still fits cus * slots_per_cu jobs.  CU b's jobs go to the positions b, b + cus, ...
+// (CUs with the most jobs first, so every round of `cus` positions is a prefix).  Empty when the layer does not fit one round.
+std::vector<JobDesc> jobs_balanced(const BatchedPlan& p, int n_rows, int family, int cus, int slots_per_cu, int min_level,
+                                   const JobModel& model = JobModel(), double tol = 0.03);
 // Lists of several dispatch rounds.  In longest-first order the first round is `slots` jobs of ONE length: they end together,
 // their successors start together (all in their start-up and first operand burst at once) and end together again.  spread_order
 // hands `frac` of the first round's slots to ALL lengths of the list in proportion to their counts (a job of duration D only has

@@ -164,8 +164,9 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "jobs.xcd_head"    fraction (default 0 = off; measured, no gain) of a list that is ALSO offered to the timing in XCD-locality order: every
  *                      XCD gets the jobs of one contiguous range of latent rows, all tap classes of a row range next to each other
  *                      in time, so that their shared input rows stay in that XCD's L2 (a permutation of the list)
- *   "jobs.balance"     1 (default): a list that fits the resident slots is also offered to the timing as per-CU sets of equal
- *                      predicted work (dg_plan.h balance_order; +0.75 % at the reference's 500 rows, profiles/r05_ab_list_orders.txt)
+ *   "jobs.balance"     1 (default): layers that fit ONE dispatch round are also offered to the timing as lists whose jobs are placed
+ *                      -- and, where the round has room, cut -- so that every CU carries the same predicted work (dg_plan.h
+ *                      balance_order, jobs_balanced; +2.2 % at the reference's 500 rows, profiles/r05_ab_list_orders.txt)
  *   "jobs.prio"        wave priorities by predicted job length (s_setprio per job): 0 (default) never, 1 the fastest lists are timed
  *                      again with them, 2 always.  Measured: the launches last the same (profiles/r05_ab_prio.txt)
  *   "jobs.spread"      1: the first dispatch round of a multi-round list mixes all job lengths (dg_plan.h spread_order).  Default 0:

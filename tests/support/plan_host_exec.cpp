@@ -133,6 +133,12 @@ int dgp2_make_recorded(void* h, const char* op, int n_rows, int cus, int slots_p
     std::memcpy(line, t.c_str(), t.size() + 1);
     return r.n_jobs;
 }
+// The work-balanced single-round list (dg_plan.h jobs_balanced) becomes the current list; returns its length (0 = does not fit one round)
+int dgp2_make_balanced(void* h, int n_rows, int cus, int slots_per_cu, int min_level) {
+    Batched& b = *static_cast<Batched*>(h);
+    b.jobs = dg::jobs_balanced(b.plan, n_rows, b.family, cus, slots_per_cu, min_level);
+    return (int)b.jobs.size();
+}
 // Wave priorities by predicted job length on the current list (dg_plan.h assign_priorities); out = the priority of every job
 void dgp2_assign_priorities(void* h, int cus, int slots_per_cu, int mode, int* out) {
     Batched& b = *static_cast<Batched*>(h);

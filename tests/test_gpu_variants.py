@@ -85,6 +85,8 @@ BITWISE = {
               {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.tune": 0}, {"jobs.tune": 0, "jobs.slots0": 5, "jobs.rate2": 300},
               # wave priorities by predicted job length: on every list / never (the default offers them to the timing)
               {"jobs.prio": 2}, {"jobs.prio": 2, "jobs.min_level": 1, "jobs.tune": 0}, {"jobs.prio": 0},
+              # without the single-round candidates (balance_order, jobs_balanced) of the timing
+              {"jobs.balance": 0},
               # the latent turn: position-batched kernel instead of the weight-stationary ones; other workgroup counts
               {"latent_turn": 0}, {"lin_groups_fwd": 3, "lin_groups_bwd": 5}, {"lin_groups_fwd": 64, "lin_groups_bwd": 64},
               # the momentum update folded into the Linear backward launch (last-arriving K slice), alone / with other group counts /

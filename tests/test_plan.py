@@ -44,6 +44,7 @@ def lib():
                                      C.c_double, C.c_char_p, C.c_int]
     l.dgp2_rebuild_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
     l.dgp2_job_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_make_balanced.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     l.dgp2_assign_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     l.dgp2_format_with_prio.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
     return l
@@ -600,4 +601,65 @@ def test_k_pair_jobs_split_the_taps_of_the_long_classes_in_two(lib):
                     if 0 <= i < 7 and 0 <= j < 7:
                         ref[:, oh, ow, :] += dy[:, i, j, :] @ Ft[kh * 5 + kw].T
     np.testing.assert_allclose(out, np.where(gate, ref, 0.0), rtol=1e-10, atol=1e-10)
+    lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_jobs_balanced_builds_a_single_round_list_of_equal_work_per_cu(lib):
+    """dg_plan.h jobs_balanced (TuneRecord.snake = 4): a list for ONE dispatch round -- at most cus * slots_per_cu jobs, CU b's jobs at
+    the positions b, b + 256, ... -- whose tiles are cut (along M / N only) until the heaviest CU carries at most a few percent more
+    than the mean.  CelebA's 4x4 <- 8x8 backward at 1280 rows as whole tiles is 480 jobs for 256 CUs: 32 CUs would hold one job.
+    Every output element is still written exactly once with the right value; the record rebuilds the list; a layer that does not
+    fit one round gives no list."""
+    rs = np.random.RandomState(12)
+    h1, h2, info, b = batched(lib, "deconv_bwd", 4, 4, 8, 8, 256, 128, 256)
+    n_rows, cus, spc = 1280, 256, 2
+    n = lib.dgp2_make_balanced(h2, n_rows, cus, spc, 0)
+    assert 480 < n <= cus * spc
+    jobs = (C.c_int * (6 * n))(); lib.dgp2_jobs(h2, jobs)
+    jobs = np.array(jobs).reshape(n, 6)
+    pr = (C.c_int * (4 * n))(); lib.dgp2_job_pairs(h2, pr)
+    own = np.array(pr).reshape(n, 4)[:, 0]
+    work = own * np.array([128 * 128, 64 * 128, 64 * 64])[jobs[:, 1]]
+    per_cu = np.array([work[c::cus].sum() for c in range(cus)])               # (rounds are prefixes: position r * 256 + b is CU b's r-th job)
+    assert (np.bincount(np.arange(n) % cus, minlength=cus) <= spc).all()
+    over = lambda w: (w.max() - w.mean()) / w.mean()
+    print("heaviest CU above the mean: balanced %.3f" % over(per_cu))
+    # whole tiles in longest-first order: the same measure
+    plain = jobs_of(lib, h2, n_rows, cus * spc, 1e30)
+    pr0 = (C.c_int * (4 * len(plain)))(); lib.dgp2_job_pairs(h2, pr0)
+    w0 = np.array(pr0).reshape(-1, 4)[:, 0] * np.array([128 * 128, 64 * 128, 64 * 64])[plain[:, 1]]
+    per_cu0 = np.array([w0[c::cus].sum() for c in range(cus)])
+    print("heaviest CU above the mean: whole tiles, longest first %.3f" % over(per_cu0))
+    # (two slots per CU at this level and 480 whole tiles: only 32 cuts fit the round -- the balance improves, it cannot become flat)
+    assert over(per_cu) < 0.75 * over(per_cu0)
+    # with room to cut (quarters, five slots per CU) the heaviest CU ends within a few percent of the mean
+    n5 = lib.dgp2_make_balanced(h2, 500, cus, 5, 2)
+    j5 = (C.c_int * (6 * n5))(); lib.dgp2_jobs(h2, j5); j5 = np.array(j5).reshape(n5, 6)
+    p5 = (C.c_int * (4 * n5))(); lib.dgp2_job_pairs(h2, p5)
+    w5 = np.array(p5).reshape(n5, 4)[:, 0] * np.array([128 * 128, 64 * 128, 64 * 64])[j5[:, 1]]
+    cu5 = np.array([w5[c::cus].sum() for c in range(cus)])
+    print("500 rows, quarters: %d jobs, heaviest CU above the mean %.3f" % (n5, over(cu5)))
+    assert 0 < n5 <= cus * 5 and over(cu5) < 0.12
+    # correctness of the cut list (small row count so that the host executor is quick)
+    n_small = lib.dgp2_make_balanced(h2, 60, 16, 5, 1)
+    assert n_small > 0
+    dy = rs.randn(60, 8, 8, 128); Ft = rs.randn(25, 256, 128)
+    out = rs.rand(60, 4, 4, 256) - 0.3
+    gate = out > 0
+    touched = apply_jobs(lib, h2, dy, Ft, None, out, 3)
+    assert (touched == 1).all()
+    ref = np.zeros((60, 4, 4, 256))
+    for oh in range(4):
+        for ow in range(4):
+            for kh in range(5):
+                for kw in range(5):
+                    i, j = 2 * oh + kh - 1, 2 * ow + kw - 1
+                    if 0 <= i < 8 and 0 <= j < 8:
+                        ref[:, oh, ow, :] += dy[:, i, j, :] @ Ft[kh * 5 + kw].T
+    np.testing.assert_allclose(out, np.where(gate, ref, 0.0), rtol=1e-10, atol=1e-10)
+    # the tuning record (order code 4) rebuilds the list; a layer too big for one round has no such list
+    line = C.create_string_buffer(256)
+    n2 = lib.dgp2_make_recorded(h2, b"B2", n_rows, cus, spc, 0, 0.0, 4, 0.0, 0.0, line, 256)
+    assert n2 == n and lib.dgp2_rebuild_matches(h2, line.value, 0, cus, spc) == 1
+    assert lib.dgp2_make_balanced(h2, 12500, cus, spc, 0) == 0
     lib.dgp2_free(h2); lib.dgp_free(h1)
