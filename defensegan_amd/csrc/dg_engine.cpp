@@ -79,6 +79,7 @@ struct JobList {
     double slack = 0.0;            // the cutting threshold the list was built with (dg_plan.h build_jobs)
     double taper = 0.0;            // JobModel::taper the list was built with
     int prio = 0;                  // 1 = wave priorities by predicted job length (dg_plan.h assign_priorities)
+    int pair_kernel = 0;           // 1 = launched as the PAIR instantiation although it holds no pair (dg_plan.h TuneRecord::pair_kernel)
     double xcd_head = 0.0;         // head fraction of the XCD-locality order
     double predicted_us = 0.0;     // simulated makespan of the cost model
     double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
@@ -168,6 +169,12 @@ struct dg_handle {
     // Batchnorm forward statistics from the producing GEMM's epilogue (per-32-row-block column sums, EPI_BIAS_STATS) instead of a
     // pass over the pre-activations; 0 = the separate pass (cross-check)
     int bn_fused = 1;
+    // The kernel has two instantiations per (family, epilogue, level): with and without the K-pair hand-off code.  A list without
+    // pairs needs neither, and hipcc allocates and schedules their main loops differently: measured on MNIST at 2560 rows the PAIR
+    // form is 0.7 % FASTER on Generator.3's backward and 0.6 % on Generator.2's forward, 0.3 % slower on Generator.3's forward
+    // (profiles/r05_ab_pair_kernel.txt).  1 = the two fastest lists without pairs are timed on both and the faster form is kept
+    // (default), 0 = never, 2 = always.
+    int job_pair_kernel = 1;
     int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
     // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
     // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
@@ -489,6 +496,9 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.jobs = jl.d_jobs;
     a.pair_scratch = jl.d_pair ? jl.d_pair + (size_t)group * jl.pair_stride : nullptr;
     a.pair_count = jl.d_pair_count ? jl.d_pair_count + (size_t)group * jl.pair_count_stride : nullptr;
+    // a list without pairs that was timed faster on the PAIR instantiation (same arithmetic, another register allocation): any
+    // non-null pointer selects it, nothing reads it
+    if (jl.pair_kernel && !a.pair_scratch) a.pair_scratch = reinterpret_cast<float*>(jl.d_jobs);
     a.cls = op.d_cls;
     a.taps = op.d_btaps;
     a.pos_a = op.d_pos_a;
@@ -580,6 +590,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             jm.taper = tapers[k];
             c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
                                     jm, &c.jl.predicted_us, lvl);
+            if (h->job_pair_kernel >= 2) c.jl.pair_kernel = 1;
             if (h->job_prio >= 2) {
                 c.jl.prio = 1;
                 dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], jm, 1);
@@ -715,6 +726,23 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 cands.push_back(std::move(c));
             }
         }
+        if (ok && h->job_pair_kernel >= 1) {
+            // the two fastest lists without K-pair jobs, once more on the PAIR instantiation of the kernel
+            std::vector<size_t> top;
+            for (size_t i = 0; i < cands.size(); ++i)
+                if (cands[i].ms < 1e29f && cands[i].jl.d_jobs && !cands[i].jl.d_pair) top.push_back(i);
+            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
+            if (top.size() > 2) top.resize(2);
+            for (size_t k = 0; ok && k < top.size(); ++k) {
+                Cand c;
+                c.jl = cands[top[k]].jl;
+                c.jl.d_jobs = nullptr;
+                c.jl.pair_kernel = 1;
+                c.jobs = cands[top[k]].jobs;
+                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
+                cands.push_back(std::move(c));
+            }
+        }
         if (ok && h->job_prio == 1) {
             // the three fastest lists so far, once more with wave priorities by predicted job length (same jobs, same order)
             std::vector<size_t> top;
@@ -767,7 +795,13 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                     // finalists within 0.7 % of each other are a coin toss from run to run (seen: Generator.2's backward taking a
                     // level-0 list in one process and a level-1 list in the next): then the cost model's favourite among them is
                     // kept, so that two runs on the same device make the same choice unless one list is measurably faster
-                    if (sum[pref] <= 1.007f * sum[w]) w = pref;
+                    // (not between the two kernel forms of ONE list: there the timing compares like with like, and either choice
+                    // gives the same results)
+                    auto same_list = [&](const JobList& a, const JobList& b) {
+                        return a.min_level == b.min_level && a.slack == b.slack && a.taper == b.taper && a.snake == b.snake &&
+                               a.xcd_order == b.xcd_order && a.prio == b.prio && a.n_jobs == b.n_jobs;
+                    };
+                    if (sum[pref] <= 1.007f * sum[w] && !same_list(cands[fin[pref]].jl, cands[fin[w]].jl)) w = pref;
                     best = fin[w];
                 }
             }
@@ -776,7 +810,7 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
                 for (size_t i = 0; i < cands.size(); ++i)
                     if (cands[i].ms < 1e29f)
                     fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 4 ? " built" : cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.prio ? " prio" : "     ",
+                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 4 ? " built" : cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.pair_kernel ? " pk  " : cands[i].jl.prio ? " prio" : "     ",
                             cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
                             i == best ? "  <- kept" : "");
             }
@@ -1664,7 +1698,7 @@ int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
             dg::TuneRecord r;
             r.op = op.name; r.n_rows = jl.n_rows; r.min_level = jl.min_level; r.slack = jl.slack; r.snake = jl.snake;
             r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us; r.taper = jl.taper;
-            r.prio = jl.prio;
+            r.prio = jl.prio; r.pair_kernel = jl.pair_kernel;
             out += dg::format_tune_record(r);
         }
     };
@@ -1702,11 +1736,11 @@ int dg_import_tuning(dg_handle* h, const char* text) {
         }
         GemmOp* op = nullptr;
         for (GemmOp* o : ops) if (o->name == r.op) op = o;
-        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2 || r.prio < 0 || r.prio > 1)
+        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2 || r.prio < 0 || r.prio > 1 || r.pair_kernel < 0 || r.pair_kernel > 1)
             return fail(DG_E_INVALID, "tuning record for unknown layer '%s' / bad row count %d / level %d", r.op.c_str(), r.n_rows, r.min_level);
         JobList jl;
         jl.n_rows = r.n_rows; jl.min_level = r.min_level; jl.slack = r.slack; jl.snake = r.snake; jl.xcd_order = r.xcd_order;
-        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper; jl.prio = r.prio;
+        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper; jl.prio = r.prio; jl.pair_kernel = r.pair_kernel;
         const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(op->bplan, op->family, h->cu_count, h->job_slots_per_cu[op->family][r.min_level],
                                                                    r, h->job_model, &jl.predicted_us);
         if ((int)jobs.size() != r.n_jobs)
@@ -1863,7 +1897,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
         k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
-        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance" || k == "jobs.spread") {
+        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance" || k == "jobs.spread" || k == "jobs.pair_kernel") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
         const double v = atof(value);
@@ -1876,6 +1910,7 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         else if (k == "jobs.taper") h->job_model.taper = v;
         else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
         else if (k == "jobs.balance") h->job_balance = v != 0.0;
+        else if (k == "jobs.pair_kernel") h->job_pair_kernel = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
         else if (k == "jobs.spread") h->job_spread = v != 0.0;
         else if (k == "jobs.prio") h->job_prio = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
         else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }

@@ -587,8 +587,8 @@ void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int fam
 
 std::string format_tune_record(const TuneRecord& r) {
     char line[256];
-    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f %.17g %d\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
-             r.xcd_head, r.n_jobs, r.measured_us, r.taper, r.prio);
+    snprintf(line, sizeof line, "%s %d %d %.17g %d %d %.17g %d %.3f %.17g %d %d\n", r.op.c_str(), r.n_rows, r.min_level, r.slack, r.snake, r.xcd_order,
+             r.xcd_head, r.n_jobs, r.measured_us, r.taper, r.prio, r.pair_kernel);
     return line;
 }
 
@@ -613,7 +613,14 @@ bool parse_tune_record(const char** pp, TuneRecord* r) {
             q = p + used;
             while (*q == ' ' || *q == '\t') ++q;
             int pr = 0, u3 = 0;
-            if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%d%n", &pr, &u3) == 1 && u3 > 0) { t.prio = pr; used = (int)(q - p) + u3; }
+            if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%d%n", &pr, &u3) == 1 && u3 > 0) {
+                t.prio = pr; used = (int)(q - p) + u3;
+                // optional twelfth field: the kernel instantiation
+                q = p + used;
+                while (*q == ' ' || *q == '\t') ++q;
+                int pk = 0, u4 = 0;
+                if (*q && *q != '\n' && *q != '\r' && sscanf(q, "%d%n", &pk, &u4) == 1 && u4 > 0) { t.pair_kernel = pk; used = (int)(q - p) + u4; }
+            }
         }
     }
     t.op = name;

@@ -125,6 +125,8 @@ struct TuneRecord {
     double measured_us = 0.0;  // informational
     double taper = 0.0;        // JobModel::taper the list was built with (tenth field of the line; absent in round-4a texts = 0)
     int prio = 0;              // 1 = wave priorities by predicted job length (assign_priorities; eleventh field, absent = 0)
+    int pair_kernel = 0;       // 1 = the list runs the PAIR instantiation of the kernel although it holds no K-pair job (twelfth field,
+                               // absent = 0): the same arithmetic, another register allocation / schedule -- a timed choice like the rest
 };
 std::string format_tune_record(const TuneRecord& r);                 // one line, '\n'-terminated
 // Parses the record at *p and advances *p behind it; false on a malformed record (nothing consumed) or at the end of the text.

@@ -519,7 +519,7 @@ class DefenseGANBase(object):
 
 def tuning_text_id(text: str) -> str:
     """12 hex digits naming the job lists a dg_export_tuning text describes.  A record is
-    ``op n_rows min_level slack snake xcd_order xcd_head n_jobs measured_us [taper [prio]]`` (dg_plan.cpp format_tune_record):
+    ``op n_rows min_level slack snake xcd_order xcd_head n_jobs measured_us [taper [prio [pair_kernel]]]`` (dg_plan.cpp format_tune_record):
     every field but ``measured_us`` (index 8, informational: two timings of the same list differ) enters the id, the taper
     and the priority mode -- which do change the list -- included; fields an older text lacks count as 0."""
     import hashlib
@@ -532,7 +532,8 @@ def tuning_text_id(text: str) -> str:
             continue
         taper = f[9] if len(f) > 9 else "0"
         prio = f[10] if len(f) > 10 else "0"                  # eleventh field (round 5): wave priorities by job length
-        keys.append(" ".join(f[:8] + ["%.17g" % float(taper), str(int(prio))]))
+        pairk = f[11] if len(f) > 11 else "0"                 # twelfth: the list runs the PAIR instantiation of the kernel
+        keys.append(" ".join(f[:8] + ["%.17g" % float(taper), str(int(prio)), str(int(pairk))]))
     return hashlib.sha256("\n".join(sorted(keys) if keys else lines).encode()).hexdigest()[:12]
 
 

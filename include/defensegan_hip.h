@@ -167,6 +167,9 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "jobs.balance"     1 (default): layers that fit ONE dispatch round are also offered to the timing as lists whose jobs are placed
  *                      -- and, where the round has room, cut -- so that every CU carries the same predicted work (dg_plan.h
  *                      balance_order, jobs_balanced; +2.2 % at the reference's 500 rows, profiles/r05_ab_list_orders.txt)
+ *   "jobs.pair_kernel" the kernel has an instantiation with and one without the K-pair hand-off code; lists without pairs can run on
+ *                      either (same arithmetic, another register allocation): 1 (default) the two fastest lists are timed on both
+ *                      and the faster form is kept (+0.3 % on the MNIST loop, profiles/r05_ab_pair_kernel.txt), 0 never, 2 always
  *   "jobs.prio"        wave priorities by predicted job length (s_setprio per job): 0 (default) never, 1 the fastest lists are timed
  *                      again with them, 2 always.  Measured: the launches last the same (profiles/r05_ab_prio.txt)
  *   "jobs.spread"      1: the first dispatch round of a multi-round list mixes all job lengths (dg_plan.h spread_order).  Default 0:

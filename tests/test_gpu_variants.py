@@ -87,6 +87,8 @@ BITWISE = {
               {"jobs.prio": 2}, {"jobs.prio": 2, "jobs.min_level": 1, "jobs.tune": 0}, {"jobs.prio": 0},
               # without the single-round candidates (balance_order, jobs_balanced) of the timing
               {"jobs.balance": 0},
+              # every list without pairs on the PAIR instantiation of the kernel / never (the default times both forms)
+              {"jobs.pair_kernel": 2}, {"jobs.pair_kernel": 0},
               # the latent turn: position-batched kernel instead of the weight-stationary ones; other workgroup counts
               {"latent_turn": 0}, {"lin_groups_fwd": 3, "lin_groups_bwd": 5}, {"lin_groups_fwd": 64, "lin_groups_bwd": 64},
               # the momentum update folded into the Linear backward launch (last-arriving K slice), alone / with other group counts /
@@ -94,7 +96,7 @@ BITWISE = {
               {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 5}, {"update_fold": 1, "lin_groups_bwd": 64},
               {"update_fold": 1, "two_streams": 2, "two_stream_min_rows": 64}],
     "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
-               {"jobs.prio": 2}, {"jobs.prio": 0},
+               {"jobs.prio": 2}, {"jobs.prio": 0}, {"jobs.pair_kernel": 2},
                {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300},
                {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}, {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 3}],
 }

@@ -344,7 +344,10 @@ def test_tuning_records_round_trip_to_the_same_job_lists(lib):
     assert lib.dgp2_rebuild_matches(b, old.encode(), 0, 256, slots[lvl]) == 1
     # ... and one without the eleventh (before the wave priorities): priority mode 0
     ten = " ".join(line.value.decode().split()[:10]) + "\n"
-    assert len(line.value.decode().split()) == 11 and lib.dgp2_rebuild_matches(b, ten.encode(), 0, 256, slots[lvl]) == 1
+    assert len(line.value.decode().split()) == 12 and lib.dgp2_rebuild_matches(b, ten.encode(), 0, 256, slots[lvl]) == 1
+    # ... and one without the twelfth (before the kernel instantiation became a timed choice): the plain instantiation
+    eleven = " ".join(line.value.decode().split()[:11]) + "\n"
+    assert lib.dgp2_rebuild_matches(b, eleven.encode(), 0, 256, slots[lvl]) == 1
     lib.dgp2_free(b)
     lib.dgp_free(h)
 
@@ -400,6 +403,9 @@ def test_tuning_text_id_ignores_order_and_measured_durations():
     # the eleventh field, the priority mode, names another list; absent = 0
     assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0\n") == tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 2.0 0\n")
     assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 1\n") != tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0\n")
+    # the twelfth, the kernel instantiation the list runs on; absent = 0
+    assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0 0\n") == tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0\n")
+    assert tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0 1\n") != tuning_text_id(head + "F2 2560 1 0.97 0 0 0 2024 1.0 0 0 0\n")
 
 
 def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
