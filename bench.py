@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="configs[4] shape: one step = a defended evaluation of --images images sharded over the ranks")
     ap.add_argument("--images", type=int, default=10000, help="--strong: images in the evaluated list")
+    ap.add_argument("--host-io", action="store_true",
+                    help="hand the images over as a pageable host (NumPy) array and take rec / idx / loss / z back on the host every step: "
+                         "the PCIe-inclusive rate of the Python mirror (tagged io=host in the line; never the headline value)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
     ap.add_argument("--retune", action="store_true",
                     help="time the job lists on this box instead of installing the committed choice (profiles/r05_tuning_<arch>.txt)")
@@ -420,6 +423,13 @@ def main():
                 # a new batch of images every step: global row index advances, so z0 differs
                 first_row = ((i * world) + rank) * B * R
                 return gan.reconstruct(x, seed=2024, first_row=first_row, return_details=True)
+            if args.host_io:
+                if distributed:
+                    raise SystemExit("--host-io is a single-process measurement")
+                x_host = x.cpu().numpy()           # pageable, as a caller of the reference hands its images over
+
+                def step(i):
+                    return gan.reconstruct(x_host, seed=2024, first_row=i * B * R, return_details=True)
         st["x"], st["step"] = x, step
 
     # workspace + timed job lists: outside the hot call (dg_prepare); the steps below only enqueue.  With several ranks, rank 0
@@ -546,6 +556,7 @@ def main():
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0,
                        "parallelism": "shard%d" % world},
+            "io": "host (pageable NumPy in, NumPy out: PCIe-inclusive)" if args.host_io else "resident in HBM",
             "build": build_id(),
             # which job lists ran (a timed choice per layer and row count; identical ids = identical lists on every rank)
             "tuning_id": tuning_id, "tuning_id_per_rank": rank_tuning, "tuning_source": tuning_source, "prepare_ms": round(prepare_ms, 1),
@@ -560,7 +571,7 @@ def main():
             res["accuracy"] = round(float(result["acc"]), 4)
             res["mean_diff"] = round(float(result["roc"][2].mean()), 6)
         else:
-            loss = out["loss"].view(B, R).min(dim=1).values
+            loss = torch.as_tensor(out["loss"]).view(B, R).min(dim=1).values        # NumPy with --host-io
             res["mean_best_loss"] = round(float(loss.mean().item()), 6)
         if world == 1 and not args.no_cpu_baseline and not args.use_bn:
             res["cpu_baseline"] = cpu_baseline(arch, params, x[:16].cpu().numpy(), R, L)
