@@ -669,3 +669,65 @@ def test_jobs_balanced_builds_a_single_round_list_of_equal_work_per_cu(lib):
     assert n2 == n and lib.dgp2_rebuild_matches(h2, line.value, 0, cus, spc) == 1
     assert lib.dgp2_make_balanced(h2, 12500, cus, spc, 0) == 0
     lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_random_sweep_of_list_variants_covers_every_output_once_with_the_right_value(lib):
+    """Every way the engine can build a job list (dg_plan.h jobs_from_record: starting level, cutting threshold, boustrophedon /
+    balance_order / spread_order, XCD order, taper; jobs_balanced) over the geometries of both generators (with and without K-pair
+    classes), at seeded random row counts and CU counts small enough that lists span several dispatch rounds: the host executor
+    writes every output element exactly once and reproduces the dense oracle.  36 seeded draws."""
+    rs = np.random.RandomState(2025)
+    geoms = [("deconv_fwd", 4, 7), ("deconv_fwd", 4, 8), ("deconv_fwd", 7, 14), ("deconv_fwd", 8, 16),
+             ("deconv_bwd", 4, 7), ("deconv_bwd", 4, 8), ("deconv_bwd", 7, 14), ("deconv_bwd", 8, 16)]
+    slots = {0: 2, 1: 3, 2: 5}
+    seen_pairs = seen_balanced = 0
+    for draw in range(36):
+        kind, h_in, e = geoms[draw % len(geoms)]
+        fwd = kind == "deconv_fwd"
+        cin, cout = (int(rs.choice([64, 128])), int(rs.choice([64, 128]))) if draw % 3 else (256, 128)
+        if h_in >= 7:                                     # the big grids: keep the executor quick
+            cin, cout = min(cin, 128), 64
+        bn = cout if fwd else cin                         # as the engine builds its plans: one column block = all output channels
+        n_rows = int(rs.randint(1, 70))
+        cus = int(rs.choice([4, 8, 16]))
+        balanced = rs.rand() < 0.3
+        if balanced:                                      # a single-round list: more pieces than CUs, at most cus * slots jobs
+            n_rows = int(rs.randint(1, 24))
+        lvl = int(rs.randint(0, 3))
+        h1, h2, info, b = batched(lib, kind, h_in, h_in, e, e, cin, cout, bn)
+        if balanced:
+            n = 0
+            for cus in (4, 8, 16, 32, 64, 128, 256):      # the first CU count at which the layer fits one round
+                n = lib.dgp2_make_balanced(h2, n_rows, cus, slots[lvl], lvl)
+                if n:
+                    assert cus < n <= cus * slots[lvl]
+                    seen_balanced += 1
+                    break
+            if n == 0:                                    # no such CU count (fewer pieces than CUs everywhere): the plain list instead
+                n = lib.dgp2_make_jobs(h2, n_rows, cus * slots[lvl], 0.0)
+        else:
+            slack = float(rs.choice([1e30, 1.04, 0.9, 0.0]))
+            snake = int(rs.choice([0, 1, 2, 3]))
+            xhead = float(rs.choice([0.0, 0.0, 0.5]))
+            taper = float(rs.choice([0.0, 0.0, 0.65]))
+            line = C.create_string_buffer(256)
+            n = lib.dgp2_make_recorded(h2, b"XX", n_rows, cus, slots[lvl], lvl, slack, snake, xhead, taper, line, 256)
+            assert lib.dgp2_rebuild_matches(h2, line.value, 0, cus, slots[lvl]) == 1
+        assert n > 0
+        pr = (C.c_int * (4 * n))(); lib.dgp2_job_pairs(h2, pr)
+        seen_pairs += int((np.array(pr).reshape(n, 4)[:, 1] != 0).any())
+        if fwd:
+            x = rs.randn(n_rows, h_in, h_in, cin); F = rs.randn(5, 5, cout, cin); bias = rs.randn(cout)
+            out = np.full((n_rows, e, e, cout), 777.0)
+            touched = apply_jobs(lib, h2, x, F, bias, out, 2)
+            want = np.maximum(O.deconv2d(x, F, bias, e), 0)
+        else:
+            dy = rs.randn(n_rows, e, e, cout); F = rs.randn(5, 5, cout, cin)
+            hact = rs.rand(n_rows, h_in, h_in, cin) - 0.3
+            out = hact.copy()
+            touched = apply_jobs(lib, h2, dy, np.ascontiguousarray(F.transpose(0, 1, 3, 2)), None, out, 3)
+            want = O.deconv2d_backward_input(dy, F, h_in) * (hact > 0)
+        assert (touched == 1).all(), (draw, kind, h_in, e, cin, cout, bn, n_rows, cus, lvl)
+        np.testing.assert_allclose(out, want, rtol=1e-10, atol=1e-10, err_msg=str((draw, kind, h_in, e, cin, cout, bn, n_rows, cus, lvl)))
+        lib.dgp2_free(h2); lib.dgp_free(h1)
+    assert seen_pairs >= 2 and seen_balanced >= 3         # the sweep met K-pair lists and single-round balanced lists
