@@ -3,8 +3,8 @@
 
     python tools/gemm_loop_isa.py [substring of the demangled kernel name ...] > profiles/rNN_gemm_loop_isa.txt
 
-A K loop = a loop (LLVM's own block annotations) that holds MFMA instructions; one iteration = TWO 32-float K chunks (the double
-buffer unrolled) of the job's tile shape (dg_gemm.hip run_job: one loop per tile shape an instantiation can run).  Per loop: instructions by class -- what DESIGN 4.1 states about the inner loop (per chunk and
+A K loop = a loop (LLVM's own block annotations) that holds MFMA instructions; one iteration = one 32-float K chunk
+of the job's tile shape (dg_gemm.hip run_job: one loop per tile shape an instantiation can run).  Per loop: instructions by class -- what DESIGN 4.1 states about the inner loop (per chunk and
 wave 64 v_mfma_f32_32x32x2_f32 on a 128x128 tile, 16 ds_read_b128, 8 LDS-DMA loads, one barrier) can be read off here, and so can
 the difference between the two forms (PAIR = true / false) of an instantiation that jobs.pair_kernel chooses between."""
 import os
