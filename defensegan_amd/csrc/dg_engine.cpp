@@ -88,11 +88,19 @@ struct JobList {
     unsigned* d_pair_count = nullptr;
     float* d_pair = nullptr;
     size_t pair_count_stride = 0, pair_stride = 0;   // elements per copy: one copy per concurrent row group (option two_streams)
+    int pair_copies = 0;           // copies of the counters / images behind the job records (0 = the list has no pair)
+};
+
+// Job list of a fragment-order launch (dg_fgemm.hip): a pure function of (layer plan, row count), no timing
+struct FragList {
+    int n_rows = 0, n_jobs = 0;
+    dg::FragJob* d_jobs = nullptr;
 };
 
 struct GemmOp {
     std::string name;
     dg::BatchedPlan bplan;
+    std::vector<FragList> fjobs;
     int family = 0;
     dg::ClassDesc* d_cls = nullptr;
     dg::TapEntry* d_btaps = nullptr;
@@ -134,6 +142,15 @@ struct dg_handle {
     float* lin_pack_bwd = nullptr;
     std::vector<float> lin_w_host; // [latent][lin_out]: the packs are rebuilt when nsplit changes
     std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
+    std::vector<float*> Fp;            // per non-final deconv: the forward filters in fragment order (dg_fgemm.hip), per tap slab
+                                       // [cout / 32][cin / 8][64][4]
+    // The fragment-order forward path (round 6; option frag_path, default on; conditions: frag_active()): F1 writes h1 in fragment
+    // order + gate bits, every forward deconv runs on dg_fgemm.hip (fragment-order input; output in fragment order, or NHWC for the
+    // layer the tail reads), the backward GEMMs take their ReluGrad gates from the bits and write the gradients into the NHWC buffers.
+    int frag_path = 0;
+    const unsigned* tune_gates = nullptr;   // set while prepare_rows times a backward layer's lists: the gate bits it will run with
+    std::vector<float*> actf;          // per activation d < nd - 1: fragment-order buffer (rows padded to 32)
+    std::vector<unsigned*> gate;       // per activation d < nd - 1: [rows][row_floats / 32] gate bits
     float* tail_pack = nullptr;        // last deconv's filters in MFMA fragment order (forward tail GEMM)
     float* tail_pack16 = nullptr;      // same, 16x16x4 fragments of the kh-aligned tiles (CelebA forward tail)
     std::map<std::string, bool> have;
@@ -327,6 +344,9 @@ void free_batched(GemmOp& op) {
     for (auto& jl : op.jobs)
         if (jl.d_jobs) (void)hipFree(jl.d_jobs);
     op.jobs.clear();
+    for (auto& fl : op.fjobs)
+        if (fl.d_jobs) (void)hipFree(fl.d_jobs);
+    op.fjobs.clear();
     if (op.d_cls) { (void)hipFree(op.d_cls); op.d_cls = nullptr; }
     if (op.d_btaps) { (void)hipFree(op.d_btaps); op.d_btaps = nullptr; }
     if (op.d_pos_a) { (void)hipFree(op.d_pos_a); op.d_pos_a = nullptr; }
@@ -433,6 +453,8 @@ void free_workspace(dg_handle* h) {
     h->xbuf_floats = 0;
     ++h->list_epoch;                 // captured loops point into these buffers
     for (auto& a : h->act) fr(a);
+    for (auto& a : h->actf) fr(a);
+    for (auto& g : h->gate) if (g) { (void)hipFree(g); g = nullptr; }
     for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); fr(a.block_sums); }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
     if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
@@ -464,12 +486,20 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     }
     const int nd = (int)h->dec.size();
     h->act.assign(nd, nullptr);
+    h->actf.assign(nd, nullptr);
+    h->gate.assign(nd, nullptr);
     h->act_row.assign(nd, 0);
     size_t part_doubles = 0;
+    // (rows padded to whole 32-row blocks: the fragment-order kernels compute and store whole blocks)
+    const int64_t cap32 = (cap + 31) / 32 * 32;
     for (int d = 0; d < nd; ++d) {
         ActInfo& a = h->ai[d];
         h->act_row[d] = a.row_floats;
-        HIP_TRY(hipMalloc(&h->act[d], cap * a.row_floats * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->act[d], cap32 * a.row_floats * sizeof(float)));
+        if (h->frag_path && !h->use_bn && d + 1 < nd) {
+            HIP_TRY(hipMalloc(&h->actf[d], cap32 * a.row_floats * sizeof(float)));
+            HIP_TRY(hipMalloc(&h->gate[d], cap32 * (a.row_floats / 32) * sizeof(unsigned)));
+        }
         a.buf = h->act[d];
         if (a.has_bn) {
             HIP_TRY(hipMalloc(&a.xhat, cap * a.row_floats * sizeof(float)));
@@ -510,6 +540,8 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.mode = op.mode;
     a.stats = op.stats;
     a.stats_cols = op.bplan.ncols;
+    a.gate_bits = nullptr;
+    a.gate_words = 0;
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
 #ifdef DG_MEASURE
@@ -539,6 +571,7 @@ bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs, int family, 
     jl.d_pair = pn.pairs ? reinterpret_cast<float*>(base + jobs_bytes + count_bytes * (size_t)copies) : nullptr;
     jl.pair_count_stride = count_bytes / sizeof(unsigned);
     jl.pair_stride = img_bytes / sizeof(float);
+    jl.pair_copies = copies;
     if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess ||
         (pn.pairs && hipMemset(jl.d_pair_count, 0, count_bytes * (size_t)copies) != hipSuccess)) {
         (void)hipFree(jl.d_jobs);
@@ -546,6 +579,24 @@ bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs, int family, 
         return false;
     }
     return true;
+}
+
+// The arrival counters of a list's K-pair jobs return to zero by themselves (the second arrival wraps them), but a launch that died
+// between the two arrivals of a pair -- a device fault, a killed process that shared the handle's memory -- would leave a counter
+// at 1, and the FIRST arriver of the next call would then add a stale image and run the epilogue: silently wrong numbers.  Every
+// call therefore clears the counters of the lists it is about to launch, on its own stream (a few hundred bytes per list: free,
+// and capturable).  Same treatment as the folded update's counters.
+int clear_pair_counters(dg_handle* h, int n_rows, hipStream_t s) {
+    for (auto* vec : {&h->Fd, &h->Bd})
+        for (auto& op : *vec)
+            for (auto& jl : op.jobs)
+                if (jl.n_rows == n_rows && jl.d_pair_count && jl.pair_copies > 0)
+                    HIP_TRY(hipMemsetAsync(jl.d_pair_count, 0, jl.pair_count_stride * sizeof(unsigned) * (size_t)jl.pair_copies, s));
+    for (GemmOp* op : {&h->F1, &h->B1})
+        for (auto& jl : op->jobs)
+            if (jl.n_rows == n_rows && jl.d_pair_count && jl.pair_copies > 0)
+                HIP_TRY(hipMemsetAsync(jl.d_pair_count, 0, jl.pair_count_stride * sizeof(unsigned) * (size_t)jl.pair_copies, s));
+    return DG_OK;
 }
 
 // Job list of `op` for this row count (built on first use, kept on the device).
@@ -674,6 +725,11 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
         // two events holds no host submission gaps; short layers are repeated more often.
         auto time_list = [&](const JobList& jl, int scale, float* ms_out) {
             dg::GemmArgs a = gemm_args(h, op, jl, A, out);
+            if (h->tune_gates && op.mode == dg::EPI_MASK) {          // the launch this layer will really make (fragment-order path)
+                a.mode = dg::EPI_MASK_BITS;
+                a.gate_bits = h->tune_gates;
+                a.gate_words = (int)(op.bplan.out_rowstride / 32);
+            }
 #ifdef DG_MEASURE
             a.trace = nullptr;                       // candidate launches are not the traced ones
 #endif
@@ -840,6 +896,77 @@ bool lin_stationary(const dg_handle* h, const GemmOp& op) {
     return false;
 }
 
+// Does this handle run the fragment-order forward path (dg_fgemm.hip)?  Batchnorm couples rows through statistics passes that
+// read NHWC pre-activations; concurrent row groups start at rows that are not multiples of 32; everything else is a matter of
+// the layer shapes (the two generators at their default widths qualify).
+bool frag_active(const dg_handle* h) {
+    if (!h->frag_path || h->use_bn || h->two_streams > 1) return false;
+    return lin_stationary(h, h->F1) && h->F1.mode == dg::EPI_BIAS_RELU;
+}
+bool frag_shapes_ok(const dg_handle* h) {
+    const size_t nd = h->dec.size();
+    for (size_t d = 0; d + 1 < nd; ++d) {
+        if (!h->Fp[d] || !dg::frag_supported(h->Fd[d].bplan)) return false;
+        if (h->Fd[d].mode != dg::EPI_BIAS_RELU && h->Fd[d].mode != dg::EPI_BIAS) return false;
+        if (h->Fd[d].mode == dg::EPI_BIAS && d + 2 < nd) return false;    // (a layer without ReLU may only feed the tail)
+        if (h->ai[d].row_floats % 32) return false;
+    }
+    return h->lin_out % 128 == 0;
+}
+bool frag_on(const dg_handle* h) { return frag_active(h) && frag_shapes_ok(h) && h->actf.size() == h->dec.size() && h->actf[0] != nullptr; }
+
+const FragList* find_frag_jobs(const GemmOp& op, int n_rows) {
+    for (const auto& fl : op.fjobs)
+        if (fl.n_rows == n_rows) return &fl;
+    return nullptr;
+}
+
+const FragList* get_frag_jobs(GemmOp& op, int n_rows) {
+    if (const FragList* have = find_frag_jobs(op, n_rows)) return have;
+    const std::vector<dg::FragJob> jobs = dg::build_frag_jobs(op.bplan, n_rows);
+    if (jobs.empty()) return nullptr;
+    FragList fl;
+    fl.n_rows = n_rows;
+    fl.n_jobs = (int)jobs.size();
+    if (hipMalloc(&fl.d_jobs, jobs.size() * sizeof(dg::FragJob)) != hipSuccess) return nullptr;
+    if (hipMemcpy(fl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::FragJob), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(fl.d_jobs);
+        return nullptr;
+    }
+    if (op.fjobs.size() >= 16) { (void)hipFree(op.fjobs.front().d_jobs); op.fjobs.erase(op.fjobs.begin()); }
+    op.fjobs.push_back(fl);
+    return &op.fjobs.back();
+}
+
+// One forward deconv on dg_fgemm.hip: A in fragment order; Out in fragment order (+ gate bits) or NHWC (the layer the tail reads)
+int run_frag(dg_handle* h, GemmOp& op, int d, const float* A, float* Out, bool out_frag, unsigned* gates, int n_rows, hipStream_t s, bool prof) {
+    const FragList* fl = find_frag_jobs(op, n_rows);
+    if (!fl) return fail(DG_E_STATE, "layer %s has no fragment-order job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
+    dg::FragArgs a;
+    a.A = A;
+    a.Wp = h->Fp[(size_t)d];
+    a.Out = Out;
+    a.bias = op.bias;
+    a.gate_bits = gates;
+    a.jobs = fl->d_jobs;
+    a.taps = op.d_btaps;
+    a.a_rowstride = op.bplan.a_rowstride;
+    a.out_rowstride = op.bplan.out_rowstride;
+    a.gate_words = (int)(op.bplan.out_rowstride / 32);
+    a.kch = op.bplan.kch;
+    a.kc8_log2 = op.bplan.kch == 64 ? 3 : (op.bplan.kch == 128 ? 4 : 5);
+    a.mode = op.mode;
+    a.out_frag = out_frag ? 1 : 0;
+    a.n_jobs = fl->n_jobs;
+    char sym[64];
+    snprintf(sym, sizeof sym, "@fgemm_kernel<2, 4, %d, %s>", op.mode, out_frag ? "true" : "false");
+    {
+        ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
+        dg::launch_fgemm(a, s);
+    }
+    return launch_check(op.name.c_str());
+}
+
 // Fragment-order copies of the Linear weights for dg_linear.hip (forward: 128-feature column tiles of W^T; backward: the
 // nsplit K slices of W, all 128 latent columns each), built from the host copy kept by dg_set_weights.
 int build_lin_packs(dg_handle* h) {
@@ -888,9 +1015,12 @@ struct UpdateFold {
 };
 
 int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof,
-                       const UpdateFold* uf = nullptr) {
+                       const UpdateFold* uf = nullptr, float* out_frag = nullptr, unsigned* gates = nullptr) {
     const bool fwd = &op == &h->F1;
     dg::LinArgs a;
+    a.out_frag = fwd ? out_frag : nullptr;
+    a.gate_bits = fwd ? gates : nullptr;
+    a.gate_words = h->lin_out / 32;
     a.upd_z = nullptr; a.upd_m = nullptr; a.upd_count = nullptr; a.upd_lr = 0.f; a.upd_momentum = 0.f;
     if (uf && !fwd) { a.upd_z = uf->z; a.upd_m = uf->m; a.upd_count = uf->count; a.upd_lr = uf->lr; a.upd_momentum = uf->momentum; }
     a.A = A;
@@ -920,7 +1050,7 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
     a.trace = (h->d_job_trace && op.name == h->job_trace_op && a.units * a.groups * 2 <= kJobTraceCap) ? h->d_job_trace : nullptr;
 #endif
     char sym[64];
-    snprintf(sym, sizeof sym, a.upd_z ? "@lin_stationary_kernel<%d, %d, true>" : "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
+    snprintf(sym, sizeof sym, a.upd_z ? "@lin_stationary_kernel<%d, %d, true>" : a.out_frag ? "@lin_stationary_kernel<%d, %d, false, true>" : "@lin_stationary_kernel<%d, %d>", a.kch, a.mode);
     {
         ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
         dg::launch_lin_stationary(a, s);
@@ -929,16 +1059,21 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
 }
 
 // One GEMM layer: one launch with the job list prepare_rows() left for this row count.  Nothing here allocates or waits.
-int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof) {
+int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, hipStream_t s, bool prof, const unsigned* gates = nullptr) {
     if (lin_stationary(h, op)) return run_lin_stationary(h, op, A, Out, n_rows, s, prof);
     const JobList* jl = find_jobs(op, n_rows);
     if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
     int group = 0;                                   // the row group launching: its own copy of the list's pair scratch
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i)
         if (s == h->side_stream[i] && s != nullptr) group = i + 1;
-    const dg::GemmArgs a = gemm_args(h, op, *jl, A, Out, group);
+    dg::GemmArgs a = gemm_args(h, op, *jl, A, Out, group);
+    if (gates) {                                      // fragment-order path: ReluGrad from the gate bits, Out holds gradients only
+        a.mode = dg::EPI_MASK_BITS;
+        a.gate_bits = gates;
+        a.gate_words = (int)(op.bplan.out_rowstride / 32);
+    }
     char sym[64];
-    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d, %s>", op.family, op.mode, jl->min_level, a.pair_scratch ? "true" : "false");
+    snprintf(sym, sizeof sym, "@gemm_batched_kernel<%d, %d, %d, %s>", op.family, a.mode, jl->min_level, a.pair_scratch ? "true" : "false");
     {
         ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
         dg::launch_gemm(op.family, a, s);
@@ -988,7 +1123,11 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
         return rc;
     };
     for (int i = 0; i < n && !missing; ++i)
-        each_op([&](GemmOp& op, int, int, int) { if (!lin_stationary(h, op) && !find_jobs(op, rows[i])) missing = true; return 0; });
+        each_op([&](GemmOp& op, int kind, int, int) {
+            if (lin_stationary(h, op)) return 0;
+            if (kind == 1 && frag_on(h) ? !find_frag_jobs(op, rows[i]) : !find_jobs(op, rows[i])) missing = true;
+            return 0;
+        });
     if (!missing) return DG_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     // (an error from the query -- the legacy NULL stream while another stream captures in global mode -- is treated as "capturing":
@@ -1009,8 +1148,14 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
             const float* A = kind == 0 ? h->z : kind == 1 ? h->act[d] : kind == 2 ? h->act[d + 1] : h->act[0];
             float* Out = kind == 0 ? h->act[0] : kind == 1 ? h->act[d + 1] : kind == 2 ? h->act[d] : h->part;
             if (lin_stationary(h, op)) return (int)DG_OK;          // no job list: dg_linear.hip derives its grid from the row count
-            if (!get_jobs(h, op, nr, A, Out, s))
-                return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), nr);
+            if (kind == 1 && frag_on(h)) {                         // forward deconv on dg_fgemm.hip: its own kind of list, not timed
+                if (!get_frag_jobs(op, nr)) return fail(DG_E_NOMEM, "cannot build the fragment-order job list of layer %s for %d rows", op.name.c_str(), nr);
+                return (int)DG_OK;
+            }
+            h->tune_gates = (kind == 2 && frag_on(h)) ? h->gate[(size_t)d] : nullptr;
+            const JobList* got = get_jobs(h, op, nr, A, Out, s);
+            h->tune_gates = nullptr;
+            if (!got) return fail(DG_E_NOMEM, "cannot build the job list of layer %s for %d rows", op.name.c_str(), nr);
             return (int)DG_OK;
         });
         if (rc) return rc;
@@ -1053,7 +1198,9 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     // a layer with Batchnorm behind it leaves its pre-activations in the layer's own buffer (ActInfo::xhat): the BN pass writes
     // the activation
     auto out_of = [&](int d) { return (h->ai[d].has_bn ? h->ai[d].xhat : h->act[d]) + r0 * h->act_row[d]; };
-    int rc = run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
+    const bool frag = frag_on(h) && r0 == 0;
+    int rc = frag ? run_lin_stationary(h, h->F1, h->z, h->act[0], n_rows, s, prof, nullptr, h->actf[0], h->gate[0])
+                  : run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
     if (rc) return rc;
     auto bn_forward = [&](int d, const GemmOp& producer) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
@@ -1065,6 +1212,14 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     if (h->ai[0].has_bn) bn_forward(0, h->F1);
     const int nd = (int)h->dec.size();
     for (int d = 0; d + 1 < nd; ++d) {
+        if (frag) {
+            // the last of these layers feeds the tail, which reads NHWC; the others feed the next fragment-order layer
+            const bool to_tail = d + 2 == nd;
+            rc = run_frag(h, h->Fd[d], d, h->actf[d], to_tail ? h->act[d + 1] : h->actf[d + 1], !to_tail, to_tail ? nullptr : h->gate[d + 1],
+                          n_rows, s, prof);
+            if (rc) return rc;
+            continue;
+        }
         rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], out_of(d + 1), n_rows, s, prof);
         if (rc) return rc;
         if (h->ai[d + 1].has_bn) bn_forward(d + 1, h->Fd[d]);
@@ -1162,7 +1317,8 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* u
             ProfScope ps(h, g.s, prof, "BNb", 0.0);
             dg::launch_bn_backward(bn_args(h, h->ai[d + 1], g.n_rows), g.s);
         }
-        int rc = run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof);
+        int rc = run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof,
+                          frag_on(h) && r0 == 0 ? h->gate[d] : nullptr);
         if (rc) return rc;
     }
     if (h->ai[0].has_bn) {
@@ -1338,6 +1494,7 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
     h->P = h->img_h * h->img_h * h->img_c;
     const size_t ndec = h->dec.size();
     h->F.assign(ndec, nullptr);
+    h->Fp.assign(ndec, nullptr);
     h->Ft.assign(ndec, nullptr);
     h->bias.assign(ndec, nullptr);
     hipError_t e = hipSuccess;
@@ -1392,6 +1549,7 @@ int dg_destroy(dg_handle* h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& p : h->F) fr(p);
+    for (auto& p : h->Fp) fr(p);
     for (auto& p : h->Ft) fr(p);
     for (auto& p : h->bias) fr(p);
     auto frop = [](GemmOp& op) { free_batched(op); };
@@ -1466,6 +1624,19 @@ int dg_set_weights(dg_handle* h, const char* name, const float* data, const int6
                         t[((size_t)k * s.cin + ci) * s.cout + co] = host[((size_t)k * s.cout + co) * s.cin + ci];
             HIP_TRY(hipMemcpy(h->F[d], host.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(h->Ft[d], t.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            if (d + 1 < h->dec.size() && s.cout % 32 == 0 && s.cin % 8 == 0) {
+                // forward filters in fragment order (dg_fgemm.hip): the slab of tap k keeps its float offset k * cout * cin; inside it
+                // [cout / 32][cin / 8][64 lanes][4]: lane = ((ci % 8) / 4) * 32 + co % 32, element ci % 4
+                std::vector<float> pk((size_t)n);
+                const int kc8 = s.cin / 8;
+                for (int k = 0; k < 25; ++k)
+                    for (int co = 0; co < s.cout; ++co)
+                        for (int ci = 0; ci < s.cin; ++ci)
+                            pk[(size_t)k * s.cout * s.cin + (((size_t)(co / 32) * kc8 + ci / 8) * 64 + ((ci % 8) / 4) * 32 + co % 32) * 4 + ci % 4] =
+                                host[((size_t)k * s.cout + co) * s.cin + ci];
+                if (!h->Fp[d]) HIP_TRY(hipMalloc(&h->Fp[d], (size_t)n * sizeof(float)));
+                HIP_TRY(hipMemcpy(h->Fp[d], pk.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+            }
             if (d + 1 == h->dec.size()) {
                 // tail forward GEMM: B fragments of v_mfma_f32_32x32x2_f32 in load order.  kappa = (kh*5+kw)*cout + co is
                 // the row of host[] (layout [25][cout][cin] == [kappa][c]); lane = (kappa & 31) + 32*half holds
@@ -1570,6 +1741,12 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     RowGroup grp[dg_handle::kMaxGroups];
     const int ngroups = split_groups(h, B, R, grp);
     grp[0].s = s;
+    // (likewise the arrival counters of the K-pair jobs, before the side streams fork off this one)
+    for (int gi = 0; gi < ngroups; ++gi) {
+        bool seen = false;
+        for (int gj = 0; gj < gi; ++gj) seen = seen || grp[gj].n_rows == grp[gi].n_rows;
+        if (!seen) { rc = clear_pair_counters(h, grp[gi].n_rows, s); if (rc) return rc; }
+    }
     if (ngroups > 1) {
         for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = h->side_stream[gi - 1];
         HIP_TRY(hipEventRecord(h->ev_fork, s));
@@ -1667,6 +1844,8 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     rc = prepare_rows(h, n_rows, &n_rows, 1, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(h->z, z, (size_t)n_rows * h->latent * sizeof(float), hipMemcpyDeviceToDevice, s));
+    rc = clear_pair_counters(h, n_rows, s);
+    if (rc) return rc;
     RowGroup g; g.n_rows = n_rows; g.s = s;
     rc = run_forward(h, x, g, R, /*want_y=*/out_y != nullptr, /*want_loss=*/out_loss != nullptr, /*tail_backward=*/out_dz != nullptr, false);
     if (rc) return rc;
@@ -1803,6 +1982,18 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
     else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
         const int d = w[3] - '0';
         if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
+        if (src && frag_on(h) && d + 1 < (int)h->act.size()) {
+            // the fragment-order path keeps this activation in fragment order: hand it over as NHWC rows
+            const int64_t cnt = n < avail ? n : avail;
+            const int64_t rows = (cnt + h->act_row[d] - 1) / h->act_row[d];
+            float* tmp = nullptr;
+            HIP_TRY(hipMalloc(&tmp, (size_t)rows * h->act_row[d] * sizeof(float)));
+            dg::launch_unfrag(h->actf[d], tmp, rows, h->act_row[d], nullptr);
+            hipError_t e = hipMemcpy(dst, tmp, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice);
+            (void)hipFree(tmp);
+            if (e != hipSuccess) return fail(DG_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+            return cnt;
+        }
     }
     if (!src) return fail(DG_E_INVALID, "unknown buffer '%s'", what);
     const int64_t cnt = n < avail ? n : avail;
@@ -1860,6 +2051,14 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         h->bn_fused = atoi(value) != 0;
         drop_job_lists(h);
         return rebuild_plans(h);
+    }
+    if (k == "frag_path") {              // 1 = fragment-order forward path (dg_fgemm.hip; default), 0 = every GEMM on dg_gemm.hip
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->frag_path = atoi(value) != 0;
+        free_workspace(h);               // the fragment-order buffers exist only with it
+        drop_job_lists(h);               // (the backward layers' lists were timed with the other epilogue)
+        return DG_OK;
     }
     if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel
         HIP_TRY(hipSetDevice(h->device));
@@ -1960,6 +2159,25 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
 #else
         return fail(DG_E_INVALID, "option '%s' needs the measurement build of the library (libdefensegan_hip_measure.so, -DDG_MEASURE)", key);
 #endif
+    }
+    if (k == "debug.poison_pair_counters") {
+        // test hook (tests/test_gpu_variants.py): leaves every K-pair arrival counter of every list at `value`, the state a launch
+        // that died between the two arrivals of a pair would leave behind.  The next call must not care.
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        int n = 0;
+        std::vector<GemmOp*> ops = {&h->F1, &h->B1};
+        for (auto& op : h->Fd) ops.push_back(&op);
+        for (auto& op : h->Bd) ops.push_back(&op);
+        for (GemmOp* op : ops)
+            for (auto& jl : op->jobs) {
+                if (!jl.d_pair_count || jl.pair_copies <= 0) continue;
+                const std::vector<unsigned> v(jl.pair_count_stride * (size_t)jl.pair_copies, (unsigned)atoi(value));
+                HIP_TRY(hipMemcpy(jl.d_pair_count, v.data(), v.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                ++n;
+            }
+        if (!n) return fail(DG_E_STATE, "debug.poison_pair_counters: no prepared job list holds K-pair jobs");
+        return DG_OK;
     }
     if (k == "nsplit") {
         const int v = atoi(value);

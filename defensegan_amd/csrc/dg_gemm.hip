@@ -190,6 +190,24 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                 }
         }
     };
+    // EPI_MASK_BITS: the gate words of this lane's rows (one 32-column group per (j)), fetched during the last K chunk
+    unsigned gatew[TM][TN][4];
+    const unsigned* gate_base = g.gate_bits + (long long)jb.n_first * g.gate_words;
+    auto prefetch_gates = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int colb = jb.n0 + wn * (BN / WN) + j * 32;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    unsigned w = 0u;
+                    if (ovalid[i][p]) w = gate_base[(orow[i][p] + (unsigned)colb) >> 5];
+                    gatew[i][j][p] = w;
+                }
+        }
+    };
+    if (MODE == EPI_MASK_BITS && nchunks == 0) prefetch_gates();
     if (MODE == EPI_MASK && nchunks == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -248,6 +266,8 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                     if (e < slots_here) issue_slot(first + e, nx);        // slot first+e rides behind MFMA group e
                 } else if constexpr (MODE == EPI_MASK) {
                     if (kk == 0 && e == 0) prefetch_mask();
+                } else if constexpr (MODE == EPI_MASK_BITS) {
+                    if (kk == 0 && e == 0) prefetch_gates();
                 }
             }
             // pin the order: [fragment reads of kk+1] ([MFMA group] [DMA]) x slots_here [remaining MFMAs]
@@ -341,6 +361,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                     float t = v[q] + bv[q];
                     if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
                     if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
+                    if constexpr (MODE == EPI_MASK_BITS) t = ((gatew[i][j][p] >> (ec + q)) & 1u) ? t : 0.f;
                     v[q] = t;
                 }
                 if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
@@ -438,6 +459,7 @@ void launch_f(const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS: launch_fm<FAM, EPI_BIAS>(a, s); break;
         case EPI_BIAS_RELU: launch_fm<FAM, EPI_BIAS_RELU>(a, s); break;
         case EPI_BIAS_STATS: launch_fm<FAM, EPI_BIAS_STATS>(a, s); break;
+        case EPI_MASK_BITS: launch_fm<FAM, EPI_MASK_BITS>(a, s); break;
         default: launch_fm<FAM, EPI_MASK>(a, s); break;
     }
 }

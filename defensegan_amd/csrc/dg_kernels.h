@@ -41,6 +41,8 @@ enum EpiMode : int {
     EPI_MASK = 3,        // out = out_old > 0 ? acc : 0            (ReluGrad, in place over the activation)
     EPI_BIAS_STATS = 4,  // out = acc + bias[col], and per 32-row block of the class's M axis the column sums of out and out^2
                          // (GemmArgs::stats): the Batchnorm forward statistics without a pass over the pre-activations
+    EPI_MASK_BITS = 5,   // out = gate bit ? acc : 0: ReluGrad with the gates as one bit per element (GemmArgs::gate_bits) -- the
+                         // fragment-order path, whose forward activations do not live in the buffer the gradient is written to
 };
 
 // ---- position-batched gathered implicit GEMM (dg_gemm.hip) --------------------------------------
@@ -75,6 +77,9 @@ struct GemmArgs {
     // partition of the layer's rows whatever the job list looks like, every block summed in a fixed order: deterministic
     float* stats;
     int stats_cols;          // output columns per position (the Batchnorm channels)
+    // EPI_MASK_BITS: [rows][gate_words] words, bit f % 32 of word f / 32 = (activation f of the row > 0); gate_words = out_rowstride / 32
+    const unsigned* gate_bits;
+    int gate_words;
 #ifdef DG_MEASURE
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 #endif
@@ -82,6 +87,31 @@ struct GemmArgs {
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (256x64 / 128x64 / 64x64)
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
 int gemm_lds_bytes(int family, int min_level);
+
+// ---- LDS-free gathered implicit GEMM on fragment-order operands (dg_fgemm.hip; layouts: dg_types.h "fragment order") --------
+// Forward transposed convolutions whose input activation is in fragment order:
+//   Out[n, o_pos(j) + c] = epi( sum_{t in taps(class)} sum_{k < kch} A[n, a_pos(j) + a_off(t) + k] * W[w_off(t) + c * kch + k] )
+struct FragArgs {
+    const float* A;          // fragment order, a_rowstride floats per latent row
+    const float* Wp;         // filters: per tap slab (same float offsets w_off as the [cout][cin] slabs) [cout / 32][kch / 8][64][4]
+    float* Out;              // fragment order (out_frag) or plain NHWC rows
+    const float* bias;
+    unsigned* gate_bits;     // optional (EPI_BIAS_RELU): [rows][gate_words] one bit per output element, bit f % 32 of word f / 32 = out > 0
+    const FragJob* jobs;
+    const TapEntry* taps;
+    long long a_rowstride, out_rowstride;   // floats per latent row
+    int gate_words;          // out_rowstride / 32
+    int kch;                 // K extent per tap (input channels): 64, 128 or 256
+    int kc8_log2;            // log2(kch / 8)
+    int mode;                // EPI_BIAS_RELU / EPI_BIAS / EPI_STORE
+    int out_frag;
+    int n_jobs;
+#ifdef DG_MEASURE
+    int dbg;                 // timing experiments (env DG_FRAG_DBG): 1 = no epilogue, 2 = no K-split reduction
+    long long* trace;        // [n_jobs * 4][8] per-wave cycle stamps (tools/frag_trace.py)
+#endif
+};
+void launch_fgemm(const FragArgs& a, hipStream_t s);
 
 // ---- weight-stationary Linear kernels of the latent turn (dg_linear.hip) ------------------------
 // Out[n, unit*out_unit + c] = epi( sum_{k < 32*kch} A[n*a_rowstride + unit*a_unit + k] * Wunit[c][k] ),
@@ -107,6 +137,11 @@ struct LinArgs {
     // backward only, optional: the momentum update folded into this launch (dg_linear.hip, "folded update").  The workgroup
     // that stores the LAST of a 32-row block's `units` K slices sums the slices in slice order and applies ApplyMomentum to
     // upd_z / upd_m (both [n_rows][128], the rows of Out); upd_count = one arrival counter per 32-row block, zero between launches
+    // forward only, optional: the output in FRAGMENT ORDER (dg_types.h; rows padded to a multiple of 32) instead of Out, and the
+    // ReluGrad gates as one bit per element ([rows][gate_words] words, bit f % 32 of word f / 32)
+    float* out_frag;
+    unsigned* gate_bits;
+    int gate_words;
     float* upd_z;            // nullptr: partials only (momentum_update_kernel follows as its own launch)
     float* upd_m;
     unsigned* upd_count;
@@ -189,6 +224,9 @@ void launch_select(const float* loss, const float* y, int B, int R, int P, float
 // z ~ N(0, std^2), Philox4x32-10 keyed by (seed), counter (global row, column/4)
 void launch_init_latents(float* z, int64_t n_rows, int latent, uint64_t seed, int64_t first_row, float std,
                          hipStream_t s);
+
+// fragment order (dg_types.h) -> plain rows: dst[n * row_floats + f], n < n_rows (debug reads, tests)
+void launch_unfrag(const float* src, float* dst, int64_t n_rows, int64_t row_floats, hipStream_t s);
 
 // ---- BatchNorm with batch statistics (tflib/ops/batchnorm.py:80-93) ---------------------------
 // An activation buffer viewed as [rows, C] (rows = latent rows x positions); per-column mean / biased variance,

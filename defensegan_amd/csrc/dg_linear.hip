@@ -34,9 +34,14 @@ __device__ __forceinline__ int lswz(int row) { return (row >> 1) & 7; }
 // KCH: 32-float K chunks per block row (forward: latent / 32; backward: slice width / 32)
 // FOLD (backward only): the momentum update of a 32-row block rides in the workgroup that delivers the block's last K slice
 // ("folded update" below).
-template <int KCH, int MODE, bool FOLD = false>
+// FRAG (forward only): the output leaves in FRAGMENT ORDER (dg_types.h) for dg_fgemm.hip, with the ReluGrad gates as one bit per
+// element.  The MFMA operand roles are swapped for it (weights first): an accumulator then holds 4 consecutive columns of one row per
+// lane in 4 consecutive registers, which IS the fragment order -- 1 KB contiguous stores, no transposition through LDS.  Same
+// products, same k order per element.
+template <int KCH, int MODE, bool FOLD = false, bool FRAG = false>
 __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_stationary_kernel(LinArgs g) {
     static_assert(!FOLD || MODE == EPI_STORE, "the folded update belongs to the split-K backward");
+    static_assert(!FRAG || MODE == EPI_BIAS_RELU, "fragment-order output: the forward with ReLU");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BLK_BYTES = KCH * 4096;             // one 32-row block: [KCH chunks][32 rows][128 B]
     char* const epi = smem + 2 * BLK_BYTES;           // [4 waves][32 x 32 floats] transposition tiles
@@ -146,6 +151,39 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
         }
     };
 
+    // FRAG: bias of the 4 column quads this lane holds, and the write-out of a finished tile (bias, ReLU, gates, 4 x 1 KB stores)
+    f32x4 bvf[4];
+    if constexpr (FRAG) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            bvf[q4] = *reinterpret_cast<const f32x4*>(g.bias + unit * g.out_unit + wave * 32 + 8 * q4 + 4 * fh);
+            asm volatile("" : "+v"(bvf[q4]));
+        }
+    }
+    auto frag_store = [&](const f32x16& acc, int blk) {
+        const int col0 = unit * g.out_unit + wave * 32;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            g.out_frag + (long long)blk * 32 * g.out_rowstride, 0, 0x7ffffff0, 0x00020000);
+        unsigned bits = 0u;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[q4 * 4 + e] + bvf[q4][e];
+                bits |= (t > 0.f ? 1u : 0u) << (8 * q4 + 4 * fh + e);
+                v[e] = t > 0.f ? t : 0.f;
+            }
+            // (offset in the VGPR, soffset an immediate: with an SGPR soffset hipcc inserts no wait state between a 16-byte store and
+            // the next VALU write of its data registers -- on gfx950 the next quad's bias add then overwrote element 0 of lanes
+            // 12-15 of every 16 before the store had read them, whenever a second workgroup delayed the store's issue)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, lane * 16 + (col0 + 8 * q4) * 128, 0, 0);
+        }
+        // (always: the engine passes the gate buffer whenever it asks for fragment order; the wait below counts this store)
+        bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
+        if (fh == 0) g.gate_bits[((long long)blk * 32 + frow) * g.gate_words + (col0 >> 5)] = bits;
+    };
+
     // ---- folded update (FOLD).  A 32-row block of dz is complete when all `units` K-slice workgroups of its row group have
     // stored their partial tiles.  Every workgroup draws a ticket from the block's counter once ALL its waves' stores of that
     // block have been acknowledged (write-through stores, s_waitcnt vmcnt(0) in every wave, barrier, one relaxed agent-scope
@@ -221,7 +259,7 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
         f32x4 v[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) a[0][kk] = *reinterpret_cast<const f32x4*>(st + (((kk * 2 + fh) ^ a_sw) << 4));
-        if (i > 0) out_write(done);
+        if constexpr (!FRAG) { if (i > 0) out_write(done); }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
@@ -230,14 +268,17 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
                 for (int kk = 0; kk < 4; ++kk)
                     a[(c + 1) & 1][kk] = *reinterpret_cast<const f32x4*>(st + (c + 1) * 4096 + (((kk * 2 + fh) ^ a_sw) << 4));
             }
-            if (c == 0 && i > 0) out_read(v);
+            if constexpr (!FRAG) { if (c == 0 && i > 0) out_read(v); }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][kk][e], wf[c][kk][e], acc, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    if constexpr (FRAG) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[c][kk][e], a[c & 1][kk][e], acc, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][kk][e], wf[c][kk][e], acc, 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
-            if (c == (KCH > 2 ? 1 : 0) && i > 0) out_store(v, blk - g.groups);
+            if constexpr (FRAG) { if (c == (KCH > 2 ? 1 : 0) && i > 0) frag_store(done, blk - g.groups); }
+            else { if (c == (KCH > 2 ? 1 : 0) && i > 0) out_store(v, blk - g.groups); }
         }
         done = acc;
 #ifdef DG_MEASURE
@@ -257,12 +298,15 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
             // this block's stream; VMEM operations retire in order) are outstanding; then the barrier: every wave's pieces are
             // there, and every wave is done reading the buffer the block after that will be staged into
             if (i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (FRAG) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // (4 x 1 KB stores + the gate words)
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
     }
     const int last_blk = grp + (n_my - 1) * g.groups;
-    {
+    if constexpr (FRAG) {
+        frag_store(done, last_blk);
+    } else {
         f32x4 v[4];
         out_write(done);
         out_read(v);
@@ -289,14 +333,14 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
 #endif
 }
 
-template <int KCH, int MODE, bool FOLD = false>
+template <int KCH, int MODE, bool FOLD = false, bool FRAG = false>
 void launch_km(const LinArgs& a, hipStream_t s) {
     const int lds = 2 * KCH * 4096 + 4 * 4096 + (FOLD ? 16 : 0);
     static PerDeviceOnce attr;
     if (attr.need())
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE, FOLD>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE, FOLD, FRAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD, FRAG>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
 }
 
 template <int KCH>
@@ -306,6 +350,7 @@ void launch_k(const LinArgs& a, hipStream_t s) {
         else launch_km<KCH, EPI_STORE>(a, s);                // backward: split-K partials
     } else {
         if (a.mode == EPI_BIAS) launch_km<KCH, EPI_BIAS>(a, s);      // forward with Batchnorm behind it
+        else if (a.out_frag) launch_km<KCH, EPI_BIAS_RELU, false, true>(a, s);
         else launch_km<KCH, EPI_BIAS_RELU>(a, s);
     }
 }

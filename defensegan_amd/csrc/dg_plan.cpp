@@ -679,4 +679,90 @@ std::vector<JobDesc> build_jobs(const BatchedPlan& p, int n_rows, int family, in
     return best;
 }
 
+// ---- fragment-order path -------------------------------------------------------------------------------------------------------
+bool frag_tap_grid(const BatchedPlan& p, int cls, TapGrid* g) {
+    const ClassDesc& cd = p.cls[(size_t)cls];
+    const int cpt = p.kch / 32;
+    const int nt = cd.nchunks / cpt;
+    if (nt <= 0) return false;
+    const TapEntry* t = p.taps.data() + cd.tap_begin;
+    for (int nw = 1; nw <= nt; ++nw) {
+        if (nt % nw) continue;
+        TapGrid tg;
+        tg.nw = nw;
+        tg.a0 = t[0].a_off; tg.w0 = t[0].w_off;
+        tg.a_v = nw > 1 ? t[1].a_off - t[0].a_off : 0;
+        tg.w_v = nw > 1 ? t[1].w_off - t[0].w_off : 0;
+        tg.a_u = nt > nw ? t[nw].a_off - t[0].a_off : 0;
+        tg.w_u = nt > nw ? t[nw].w_off - t[0].w_off : 0;
+        bool ok = true;
+        for (int k = 0; k < nt && ok; ++k)
+            ok = t[k].a_off == tg.a0 + (k / nw) * tg.a_u + (k % nw) * tg.a_v && t[k].w_off == tg.w0 + (k / nw) * tg.w_u + (k % nw) * tg.w_v;
+        if (ok) { if (g) *g = tg; return true; }
+    }
+    return false;
+}
+
+int frag_ksplit(const BatchedPlan& p, int cls) {
+    const int nchunks = p.cls[(size_t)cls].nchunks;
+    const int kc8 = p.kch / 8;
+    int ks = nchunks >= 24 ? 4 : (nchunks >= 12 ? 2 : 1);
+    // a wave's part = n_taps * kc8 / ks k8-steps must be a multiple of the operand ring (4): ks <= kc8 / 4
+    while (ks > 1 && ks > kc8 / 4) ks >>= 1;
+    return ks;
+}
+
+bool frag_supported(const BatchedPlan& p) {
+    if (p.kch != 64 && p.kch != 128 && p.kch != 256) return false;
+    if (p.ncols % 64 || p.w_rowstride != p.kch) return false;
+    for (size_t c = 0; c < p.cls.size(); ++c) {
+        if (p.cls[c].wc <= 0 || p.cls[c].nchunks <= 0) return false;
+        if (!frag_tap_grid(p, (int)c, nullptr)) return false;
+        // offsets are used in units of 8 floats
+        if ((p.cls[c].a_base | p.cls[c].a_rs | p.cls[c].a_cs | p.cls[c].o_base | p.cls[c].o_rs | p.cls[c].o_cs) & 31) return false;
+    }
+    return p.a_rowstride % 32 == 0 && p.out_rowstride % 32 == 0;
+}
+
+std::vector<FragJob> build_frag_jobs(const BatchedPlan& p, int n_rows) {
+    constexpr int TN = 4;
+    const int nblk = (n_rows + 31) / 32;
+    const int kc8 = p.kch / 8;
+    struct Key { long long steps; int cls; };
+    std::vector<FragJob> out;
+    std::vector<int> order(p.cls.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    auto steps_of = [&](int c) { return (long long)p.cls[(size_t)c].nchunks * 4 / frag_ksplit(p, c); };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return steps_of(a) > steps_of(b); });
+    for (int c : order) {
+        const ClassDesc& cd = p.cls[(size_t)c];
+        TapGrid tg;
+        if (!frag_tap_grid(p, c, &tg)) return {};
+        const int ks = frag_ksplit(p, c);
+        const int per_job = TN * (4 / ks);                       // M blocks per job
+        const long long mblks = (long long)nblk * cd.pos_count;
+        for (long long m0 = 0; m0 < mblks; m0 += per_job)
+            for (int cb = 0; cb < p.ncols / 32; cb += 2) {
+                FragJob j = {};
+                j.mblk0 = (int)m0;
+                j.n_mblk = (int)std::min<long long>(per_job, mblks - m0);
+                j.cb0 = cb;
+                j.s = cd.pos_count;
+                j.s_magic = cd.magic;
+                j.wc = cd.wc; j.wc_magic = cd.wc_magic;
+                j.a_base = cd.a_base; j.a_rs = cd.a_rs; j.a_cs = cd.a_cs;
+                j.o_base = cd.o_base; j.o_rs = cd.o_rs; j.o_cs = cd.o_cs;
+                j.n_taps = cd.nchunks / (p.kch / 32);
+                j.ksplit = ks;
+                j.tap_nw = tg.nw;
+                j.tap_nw_magic = (unsigned)(((1ULL << 31) + (unsigned)tg.nw - 1) / (unsigned)tg.nw);
+                j.a0 = tg.a0; j.a_u = tg.a_u; j.a_v = tg.a_v;
+                j.w0 = tg.w0; j.w_u = tg.w_u; j.w_v = tg.w_v;
+                out.push_back(j);
+            }
+    }
+    (void)kc8;
+    return out;
+}
+
 }  // namespace dg

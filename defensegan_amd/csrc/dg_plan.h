@@ -162,4 +162,18 @@ void assign_priorities(const BatchedPlan& p, std::vector<JobDesc>& jobs, int fam
 // Makespan (microseconds) of greedy list scheduling of `jobs` in order on `slots` servers of 1/slots of the chip each.
 double simulate_jobs(const BatchedPlan& p, const std::vector<JobDesc>& jobs, int family, int slots, const JobModel& model);
 
+// ---- fragment-order path (dg_fgemm.hip; layouts and FragJob: dg_types.h) ------------------------------------------------------
+// The taps of a class as a grid: tap t = (u, v) = (t / nw, t % nw), a_off = a0 + u * a_u + v * a_v, w_off = w0 + u * w_u + v * w_v
+// (the valid (kh, kw) of a position are a product of two arithmetic progressions; Linear layers: one row).  false = not affine.
+struct TapGrid { int nw = 0, a0 = 0, a_u = 0, a_v = 0, w0 = 0, w_u = 0, w_v = 0; };
+bool frag_tap_grid(const BatchedPlan& p, int cls, TapGrid* g);
+// Waves that share one tile's K axis: a constant of the class (its K chunks and the layer's K extent per tap), never of the row count
+// or the list -- every output element is one fixed tree of k-ordered chains.  Every wave's part is a multiple of 4 k8-steps.
+int frag_ksplit(const BatchedPlan& p, int cls);
+// Can dg_fgemm.hip run this layer?  (every class a position grid with an affine tap grid, K extent 64 / 128 / 256, columns % 64 == 0,
+// dense filter slabs)
+bool frag_supported(const BatchedPlan& p);
+// Job list of one launch at n_rows latent rows (ceil(n_rows / 32) row blocks), longest jobs first.
+std::vector<FragJob> build_frag_jobs(const BatchedPlan& p, int n_rows);
+
 }  // namespace dg

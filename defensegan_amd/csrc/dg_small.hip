@@ -169,4 +169,23 @@ void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, 
                        nparts, 1.0f / (float)P);
 }
 
+// ---- fragment order -> plain rows (dg_types.h "fragment order"); one thread per 4 floats ---------------------------------
+__global__ __launch_bounds__(256) void unfrag_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n_quads,
+                                                     long long row_floats) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n_quads) return;
+    const long long qrow = row_floats >> 2;
+    const long long n = q / qrow;
+    const long long f = (q - n * qrow) << 2;
+    const long long blk = ((n >> 5) * row_floats + (f & ~7LL)) * 32;          // floats before the KB of (row block, f / 8)
+    const float4 v = *reinterpret_cast<const float4*>(src + blk + ((((f & 7) >> 2) * 32 + (n & 31)) << 2));
+    *reinterpret_cast<float4*>(dst + n * row_floats + f) = v;
+}
+
+void launch_unfrag(const float* src, float* dst, int64_t n_rows, int64_t row_floats, hipStream_t s) {
+    const long long n_quads = (long long)n_rows * (row_floats >> 2);
+    if (n_quads <= 0) return;
+    hipLaunchKernelGGL(unfrag_kernel, dim3((unsigned)((n_quads + 255) / 256)), dim3(256), 0, s, src, dst, n_quads, (long long)row_floats);
+}
+
 }  // namespace dg

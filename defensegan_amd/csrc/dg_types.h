@@ -74,4 +74,32 @@ struct JobDesc {         // one workgroup = one job: (class, M range, column ran
 };
 static_assert(sizeof(JobDesc) == 128, "two 64-byte scalar loads");
 
+// ---- fragment-order path (dg_fgemm.hip, round 6) ------------------------------------------------------------------------
+// FRAGMENT ORDER of an activation buffer with F floats per latent row (NHWC inside the row): rows in blocks of 32; the 8 floats
+// [8u, 8u + 8) of the 32 rows of block nb are ONE contiguous KB at byte (nb * F + 8u) * 128, laid out [k-half 2][row 32][4 floats]
+// (float f of row n: lane = ((f % 8) / 4) * 32 + n % 32, element f % 4) -- the operand of 4 consecutive v_mfma_f32_32x32x2_f32
+// for 32 rows.  Buffers are allocated for a multiple of 32 rows; the rows past the batch hold whatever the kernels computed there
+// (rows are independent; nothing reads them back).
+// One job = one workgroup of 4 waves = `4 / ksplit` wave tiles of TN = 4 M blocks x 2 channel blocks, each computed by `ksplit`
+// waves over contiguous parts of the tile's K axis.  M block mblk of a class = (row block nb = mblk / s, position j = mblk % s).
+struct FragJob {
+    int mblk0;           // first M block of the job
+    int n_mblk;          // valid M blocks (1 .. 4 * 4 / ksplit)
+    int cb0;             // first 32-channel block of the job's 64 output channels
+    int s;               // positions of the class
+    unsigned s_magic;    // ceil(2^31 / s)
+    int wc;              // the class's position grid (ClassDesc), >= 1
+    unsigned wc_magic;
+    int a_base, a_rs, a_cs, o_base, o_rs, o_cs;   // floats inside an input / output row
+    int n_taps;
+    int ksplit;          // 1, 2 or 4 (dg_plan.h frag_ksplit)
+    // the class's taps as a grid (dg_plan.h frag_tap_grid): tap t = (u, v) = (t / tap_nw, t % tap_nw) reads the input at float
+    // offset a0 + u * a_u + v * a_v behind the position's base and the filter slab at float offset w0 + u * w_u + v * w_v
+    int tap_nw;
+    unsigned tap_nw_magic;
+    int a0, a_u, a_v, w0, w_u, w_v;
+    int pad[9];
+};
+static_assert(sizeof(FragJob) == 128, "two 64-byte scalar loads");
+
 }  // namespace dg

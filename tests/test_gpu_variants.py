@@ -123,6 +123,36 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
 
 
+@pytest.mark.parametrize("arch,B,R", [("mnist", 50, 10), ("celeba", 30, 10)])
+def test_poisoned_pair_counters_cannot_reach_the_next_call(arch, B, R):
+    """K-pair hand-off (dg_gemm.hip): a launch that dies between the two arrivals of a pair leaves its counter at 1; the first
+    arriver of the next call would then add a STALE accumulator image and run the epilogue.  Every call clears the counters of the
+    lists it launches (clear_pair_counters, dg_engine.cpp): with every counter of every list poisoned (debug hook) the next
+    projection -- and the next loop body -- still reproduce the clean run bit for bit.  The hand-off itself is stressed too: the
+    same call 12 times, one after the other, bit-identical every time (a stale or torn image read across XCDs would show)."""
+    a = archs.make_arch(arch)
+    gan, p = _make(arch, R=R, L=4)
+    rs = np.random.RandomState(23)
+    x = np.asarray(gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=24)
+    z0 = synth.make_z(B * R, 128, seed=25)
+    ref = _run(gan, x, z0)
+    lg_ref = [np.asarray(v) for v in gan.loss_grad(x, z0)]
+    assert np.isfinite(ref["loss"]).all()
+    for value in (1, 1, 7):
+        gan.set_option("debug.poison_pair_counters", value)
+        got = _run(gan, x, z0)
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (value, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+        gan.set_option("debug.poison_pair_counters", value)
+        for u, v in zip([np.asarray(v) for v in gan.loss_grad(x, z0)], lg_ref):
+            assert np.array_equal(u, v), value
+    for rep in range(12):
+        got = _run(gan, x, z0)
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (rep, k)
+
+
 @pytest.mark.parametrize("B,R,L", [(256, 10, 60), (121, 10, 40), (3, 1, 25)])
 def test_folded_update_is_bit_identical_over_many_steps(B, R, L):
     """Option update_fold: the workgroup that delivers the last K slice of a 32-row block of dz applies the momentum update
