@@ -1220,13 +1220,7 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
             if (rc) return rc;
             continue;
         }
-        // TIMING EXPERIMENT (env DG_EXP_OVERLAP bit 0, wrong results): the second of two dependent deconvs launched without the
-        // queue's barrier bit -- its workgroups get slots as the first launch runs out of workgroups: the upper bound of what
-        // chaining the two launches behind arrival counters could gain
-        static const int exp_overlap = getenv("DG_EXP_OVERLAP") ? atoi(getenv("DG_EXP_OVERLAP")) : 0;
-        if ((exp_overlap & 1) && d == 1 && !prof) dg::g_gemm_any_order = 1;
         rc = run_gemm(h, h->Fd[d], h->act[d] + r0 * h->act_row[d], out_of(d + 1), n_rows, s, prof);
-        dg::g_gemm_any_order = 0;
         if (rc) return rc;
         if (h->ai[d + 1].has_bn) bn_forward(d + 1, h->Fd[d]);
     }
@@ -1323,11 +1317,8 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* u
             ProfScope ps(h, g.s, prof, "BNb", 0.0);
             dg::launch_bn_backward(bn_args(h, h->ai[d + 1], g.n_rows), g.s);
         }
-        static const int exp_overlap = getenv("DG_EXP_OVERLAP") ? atoi(getenv("DG_EXP_OVERLAP")) : 0;
-        if ((exp_overlap & 2) && d == 0 && !prof) dg::g_gemm_any_order = 1;
         int rc = run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof,
                           frag_on(h) && r0 == 0 ? h->gate[d] : nullptr);
-        dg::g_gemm_any_order = 0;
         if (rc) return rc;
     }
     if (h->ai[0].has_bn) {

@@ -17,13 +17,9 @@
 //  * The fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk and pinned there.
 #include <type_traits>
 
-#include <hip/hip_ext.h>
-
 #include "dg_kernels.h"
 
 namespace dg {
-
-int g_gemm_any_order = 0;      // EXPERIMENT: the next launch_gemm goes out without the barrier bit (hipExtAnyOrderLaunch)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -439,11 +435,7 @@ void launch_fmlp(const GemmArgs& a, hipStream_t s) {
     if (attr.need(lds))
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (g_gemm_any_order)
-        hipExtLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, nullptr, nullptr,
-                              hipExtAnyOrderLaunch, a);
-    else
-        hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_batched_kernel<FAM, MODE, MINLEVEL, PAIR>), dim3((unsigned)a.n_jobs), dim3(256), lds, s, a);
 }
 
 // a list with K-pair jobs (its scratch is set) runs the PAIR instantiation, every other list the plain one

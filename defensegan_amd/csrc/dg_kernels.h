@@ -86,7 +86,6 @@ struct GemmArgs {
 };
 // family 0: layers with >= 128 output columns (job shapes 128x128 / 64x128 / 64x64); family 1: 64 columns (256x64 / 128x64 / 64x64)
 void launch_gemm(int family, const GemmArgs& a, hipStream_t s);
-extern int g_gemm_any_order;
 int gemm_lds_bytes(int family, int min_level);
 
 // ---- LDS-free gathered implicit GEMM on fragment-order operands (dg_fgemm.hip; layouts: dg_types.h "fragment order") --------
