@@ -24,6 +24,7 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--output", required=True, help=".npy to write the reconstructions to")
     ap.add_argument("--raw", action="store_true", help="input is [0,255]: apply the reference's input transform first")
     ap.add_argument("--seed", type=int, default=11241990, help="seed of the z0 draw (whitebox.py:143)")
+    ap.add_argument("--no_coalesce", action="store_true", help="one engine call per --batch_size batch, as the reference's loop (slower, same results)")
     return ap
 
 
@@ -58,11 +59,11 @@ def main(argv=None) -> int:
     z_same = None
     if args.same_init:                                       # whitebox.py:181-183: one sigma = 1 draw reused for every batch
         z_same = np.random.RandomState(args.seed).randn(rp["batch_size"] * rp["rec_rr"], int(gan.latent_dim)).astype(np.float32)
-    out = np.empty_like(x[s:e])
-    for b0 in range(s, e, rp["batch_size"]):
-        b1 = min(e, b0 + rp["batch_size"])
-        kw = {"z_init_val": z_same[: (b1 - b0) * rp["rec_rr"]]} if z_same is not None else {}
-        out[b0 - s:b1 - s] = np.asarray(gan.reconstruct(x[b0:b1], seed=args.seed, first_row=b0 * rp["rec_rr"], **kw))
+    # the reference's loop feeds --batch_size images per session.run (blackbox.py:537-541); here runs of whole batches go to the
+    # engine in one call (same latents per batch, --same_init restarting at every batch: the same bits -- tests/test_gpu_coalesce.py --
+    # at 0.85 instead of 0.67 of the peak for the default batch of 50); with USE_BN a batch is the unit of the statistics: one call each
+    out = gan_defense.project_in_batches(gan.reconstruct, x[s:e], rp["batch_size"], rp["rec_rr"], seed=args.seed, first_image=s,
+                                         same_init_z=z_same, coalesce=False if args.no_coalesce else None)
     if world > 1:
         out = gan_defense.gather_shards(out, n)          # one tensor all_gather (RCCL over xGMI), no pickling
         dist.destroy_process_group()

@@ -49,12 +49,55 @@ def engine_batch_images(batch_size: int, rec_rr: int, n: int, target_rows: Optio
 
 def rows_are_independent(reconstruct) -> bool:
     """True when ``reconstruct`` is the bound ``reconstruct`` of an engine model without Batchnorm: every (image, restart) row
-    is then computed independently of the batch it is in -- GEMM tiles are never cut along K and z0 is keyed by the global row --
-    so ANY regrouping of the images into engine calls returns the same bits (tests/test_gpu_mnist.py
-    test_rows_are_independent_of_batching_and_deterministic).  With USE_BN the rows of a batch share its statistics
-    (tflib/ops/batchnorm.py:80-93) and the caller's batch boundaries are part of the result."""
+    is then computed independently of the batch it is in, so ANY regrouping of the images into engine calls returns the same bits
+    (tests/test_gpu_mnist.py test_rows_are_independent_of_batching_and_deterministic).  The invariant behind it: every output
+    element is a FIXED tree of k-ordered fp32 chains -- tiles are cut along M / N freely, but along K only in the two fixed halves
+    of the K-pair classes (dg_plan.h class_is_paired / pair_first_taps: functions of the layer plan alone, never of the row
+    count or the job list; tests/test_plan.py pins that) whose sum commutes -- and z0 is keyed by the global row.  With USE_BN
+    the rows of a batch share its statistics (tflib/ops/batchnorm.py:80-93) and the caller's batch boundaries are part of the
+    result."""
     owner = getattr(reconstruct, "__self__", None)
     return owner is not None and hasattr(owner, "rec_rr") and hasattr(owner, "use_bn") and not bool(owner.use_bn)
+
+
+def engine_step(reconstruct, batch_size: int, rec_rr: int, n: int, coalesce=None) -> int:
+    """Images per engine call for a caller that feeds batches of ``batch_size``: ``coalesce`` None = automatic (runs of whole
+    caller batches up to ``COALESCE_ROWS`` latent rows when ``rows_are_independent``), 0 / False = one call per caller batch (the
+    reference's loops), an integer = that many images per call (rounded down to whole caller batches)."""
+    if coalesce is None:
+        coalesce = rows_are_independent(reconstruct)
+    if coalesce is True:
+        return engine_batch_images(batch_size, rec_rr, max(n, 1))
+    if coalesce:
+        return max(1, int(coalesce) // int(batch_size)) * int(batch_size)
+    return int(batch_size)
+
+
+def same_init_rows(same_init_z, start: int, end: int, batch_size: int, rec_rr: int):
+    """--same_init (whitebox.py:181-183) for the images [start, end) of an engine call that spans several CALLER batches: every
+    caller batch starts from the first rows of the same z block."""
+    parts = [same_init_z[: (min(end, b0 + batch_size) - b0) * rec_rr] for b0 in range(start, end, batch_size)]
+    return parts[0] if len(parts) == 1 else _cat(parts)
+
+
+def project_in_batches(reconstruct: Callable, images, batch_size: int, rec_rr: int, seed: int = 11241990, first_image: int = 0,
+                       same_init_z=None, coalesce=None) -> np.ndarray:
+    """``reconstruct`` over ``images`` the way a per-batch caller would (the command line's loop, ``ReconstructionLayer`` users:
+    latents of image i = rows ``(first_image + i) * rec_rr + r`` of the seeded stream, ``same_init_z`` restarting at every caller
+    batch), with the caller batches coalesced into engine calls as in ``model_eval_gan``.  Returns the reconstructions [n, ...]."""
+    n = len(images)
+    step = engine_step(reconstruct, batch_size, rec_rr, n, coalesce)
+    out = None
+    for start in range(0, n, step):
+        end = min(n, start + step)
+        kw = {}
+        if same_init_z is not None:
+            kw["z_init_val"] = same_init_rows(same_init_z, start, end, batch_size, rec_rr)
+        rec = _np(reconstruct(images[start:end], seed=seed, first_row=(first_image + start) * rec_rr, **kw))
+        if out is None:
+            out = np.empty((n,) + tuple(rec.shape[1:]), rec.dtype)
+        out[start:end] = rec
+    return out if out is not None else np.zeros((0,) + tuple(np.shape(images)[1:]), np.float32)
 
 
 def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_images, test_labels,
@@ -88,14 +131,7 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
     if labels.ndim > 1:
         labels = labels.argmax(axis=-1)
     # images per engine call: whole caller batches (the z_init / seed bookkeeping below is per caller batch either way)
-    if coalesce is None:
-        coalesce = rows_are_independent(reconstruct)
-    if coalesce is True:
-        step = engine_batch_images(batch_size, rec_rr, max(n, 1))
-    elif coalesce:
-        step = max(1, int(coalesce) // int(batch_size)) * int(batch_size)
-    else:
-        step = int(batch_size)
+    step = engine_step(reconstruct, batch_size, rec_rr, n, coalesce)
     nb_batches = int(math.ceil(float(n) / step))
     on_device = hasattr(classifier, "eval_batch")
     preds: List = []
@@ -115,8 +151,7 @@ def model_eval_gan(reconstruct: Optional[Callable], classifier: Callable, test_i
             kw = {}
             if same_init_z is not None:
                 # --same_init (whitebox.py:181-183): every CALLER batch starts from the first rows of the same block
-                parts = [same_init_z[: (min(end, b0 + batch_size) - b0) * rec_rr] for b0 in range(start, end, batch_size)]
-                kw["z_init_val"] = parts[0] if len(parts) == 1 else _cat(parts)
+                kw["z_init_val"] = same_init_rows(same_init_z, start, end, batch_size, rec_rr)
             rec = reconstruct(x, seed=seed, first_row=(first_image + start) * rec_rr, **kw)
         else:
             rec = x

@@ -165,6 +165,21 @@ class MLP(object):
         from .gan import ReconstructionLayer
         self.rec_layer = ReconstructionLayer(model, z_init, self.input_shape, batch_size)
 
+    def model_eval(self, test_images, test_labels, batch_size: int, **kw):
+        """Accuracy of this classifier over ``test_images`` -- behind the Defense-GAN projection when ``add_rec_model`` installed
+        one -- as ``(correct, n, roc_info)``: ``gan_defense.model_eval_gan`` with the layer's model, ``z_init`` and ``rec_rr``.  THE
+        way to evaluate a defended classifier here: ``fprop`` / ``get_probs`` project whatever single batch they are handed in ONE
+        engine call and cannot coalesce across calls (the reference's ``ReconstructionLayer.fprop`` sits inside one session.run per
+        BATCH_SIZE = 50 images, utils/network_builder.py:266-271: 500 latent rows, where the loop runs at 0.67 of the peak), while
+        this routes the same per-batch semantics through runs of whole batches (0.85)."""
+        from . import gan_defense
+        rl = self.rec_layer
+        if rl is None:
+            return gan_defense.model_eval_gan(None, self, test_images, test_labels, batch_size, **kw)
+        kw.setdefault("same_init_z", rl.z_init)
+        return gan_defense.model_eval_gan(rl.rec_model.reconstruct, self, test_images, test_labels, batch_size,
+                                          rec_rr=int(rl.rec_model.rec_rr), **kw)
+
     def _forward(self, x, no_rec=False):
         import torch
         self._ensure()

@@ -60,3 +60,40 @@ def test_coalesced_evaluation_and_cache_equal_the_per_batch_loop(tmp_path, monke
         out[name] = (rec, {f: open(os.path.join(d, f), "rb").read() for f in sorted(os.listdir(d))})
     assert np.array_equal(out["per_batch"][0], out["coalesced"][0])
     assert len(out["coalesced"][1]) == N and out["per_batch"][1] == out["coalesced"][1]
+
+
+def test_command_line_and_defended_classifier_coalesce_like_the_evaluation(tmp_path):
+    """``python -m defensegan_amd`` and ``MLP.model_eval`` (the evaluation path of a classifier with ``add_rec_model``) hand runs of
+    whole --batch_size batches to the engine; ``--no_coalesce`` / ``coalesce=False`` is the reference's loop (one call per batch,
+    whitebox.py / blackbox.py feeding BATCH_SIZE = 50 images per session.run): the same bits, ``--same_init`` included."""
+    from defensegan_amd import __main__ as cli
+    R, L, N, BS = 10, 3, 130, 50
+    p = synth.make_weights("mnist", seed=1234, gain=2.0, bias_range=0.1)
+    x, _ = clean_targets(p, "mnist", N, seed=81)
+    x = synth.adversarial(x, 0.3, 0.0, 1.0, seed=82)
+    pack, inp = str(tmp_path / "generator.npz"), str(tmp_path / "x.npy")
+    np.savez(pack, **p)
+    np.save(inp, x)
+    outs = {}
+    for name, extra in (("co", []), ("per", ["--no_coalesce"]), ("co_same", ["--same_init"]), ("per_same", ["--same_init", "--no_coalesce"])):
+        out = str(tmp_path / (name + ".npy"))
+        assert cli.main(["--cfg", "mnist", "--init_path", pack, "--input", inp, "--output", out, "--rec_rr", str(R), "--rec_iters", str(L),
+                         "--batch_size", str(BS), "--seed", "5"] + extra) == 0
+        outs[name] = np.load(out)
+    assert np.isfinite(outs["co"]).all() and np.abs(outs["co"] - x).mean() < 0.3
+    assert np.array_equal(outs["co"], outs["per"]) and np.array_equal(outs["co_same"], outs["per_same"])
+    assert not np.array_equal(outs["co"], outs["co_same"])
+
+    # a defended classifier: model_eval == the loop over fprop-sized batches
+    gan, _ = make_gan("mnist", gain=2.0, bias_range=0.1, rec_rr=R, rec_iters=L)
+    y = (np.arange(N) * 7 % 10).astype(np.int64)
+    clf = nb.model_a()
+    clf.init_like_reference(seed=5)
+    zi = synth.make_z(BS * R, 128, seed=9)
+    clf.add_rec_model(gan, zi, BS)
+    got = clf.model_eval(x, y, BS)
+    preds = []
+    for b0 in range(0, N, BS):                      # the reference's loop: one fprop (one session.run) per batch
+        preds.append(np.asarray(clf.get_probs(x[b0:b0 + BS])).argmax(axis=1))
+    preds = np.concatenate(preds)
+    assert np.array_equal(got[2][1], preds) and got[0] == int((preds == y).sum()) and got[1] == N
