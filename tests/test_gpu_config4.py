@@ -70,13 +70,15 @@ try:
     gan.rec_iters = L
     mse_sel = ((rec - x) ** 2).flatten(1).mean(dim=1).cpu().numpy()
     # oracle subset: the first NB images of the shard, torch float32 and float64
-    from oracle import torch_ref as T
+    from tests.helpers import oracle_fixture, torch_runs
     xs = x[:NB].cpu().numpy()
     zs = gan.init_latents(NB * R, seed=2024, first_row=s0 * R).cpu().numpy()
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch="mnist")
-    t64 = T.reconstruct(p, xs.astype(np.float64), zs.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch="mnist", dtype=torch.float64)
-    msg, dec = distributional_tier(t32["loss"].reshape(NB, R), t64["loss"].reshape(NB, R), loss[:NB], idx[:NB])
+    fx, fin = oracle_fixture("config4_fgsm_%%d" %% NB, {"x": xs, "z0": zs}, torch_runs(p, "mnist", R, L, 10.0))
+    sub = gan.reconstruct(torch.from_numpy(fin["x"]).to(x.device), z_init_val=torch.from_numpy(fin["z0"]).to(x.device), return_details=True)
+    if np.array_equal(fin["x"], xs) and np.array_equal(fin["z0"], zs):
+        assert np.array_equal(sub["loss"].cpu().numpy().reshape(NB, R), loss[:NB])        # rows do not depend on their batch
+    msg, dec = distributional_tier(fx["l32"].reshape(NB, R), fx["l64"].reshape(NB, R), sub["loss"].cpu().numpy().reshape(NB, R),
+                                   sub["idx"].cpu().numpy())
     print("RESULT " + json.dumps({
         "backend": dist.get_backend(), "n": int(nn), "acc": c / nn, "acc2": acc2,
         "fgsm_max_move": moved, "fgsm_frac_at_eps": frac_eps, "in_range": bool(x.min().item() >= 0.0 and x.max().item() <= 1.0),

@@ -48,10 +48,11 @@ def test_full_size_properties_and_oracle_subset(arch, wseed, B, nb):
     from oracle import torch_ref as T
     lr = 3.0 if arch == "celeba" else 10.0
     gan.rec_lr = lr
-    dev = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t = T.reconstruct(p, x[:nb].astype(np.float64), z0[:nb * R].astype(np.float64), R, L, lr=lr, momentum=0.7, arch=arch,
-                      dtype=torch.float64)
+    from tests.helpers import oracle_fixture, torch_runs
+    fx, fin = oracle_fixture("fullsize_%s_%d" % (arch, nb), {"x": x[:nb], "z0": z0[:nb * R]},
+                             torch_runs(p, arch, R, L, lr, want32=False, want_rec=True))
+    dev = gan.reconstruct(fin["x"], z_init_val=fin["z0"], return_details=True)
+    t = {"rec": fx["rec64"].astype(np.float64), "loss": fx["l64"], "idx": fx["idx64"]}
     mse = ((dev["rec"] - t["rec"]) ** 2).reshape(nb, -1).mean(axis=1)
     assert (mse < 1e-4).all(), mse                                   # BASELINE: "MSE within 1e-4"
     gap = np.sort(t["loss"].reshape(nb, R), axis=1)

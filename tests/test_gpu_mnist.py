@@ -186,8 +186,11 @@ def test_full_size_contractive_regime_properties():
     import torch
     from oracle import torch_ref as T
     nb = 32
-    t = T.reconstruct(p, x[:nb].astype(np.float64), z0[:nb * R].astype(np.float64), R, L, lr=10.0, momentum=0.7, arch="mnist",
-                      dtype=torch.float64)
+    from tests.helpers import oracle_fixture, torch_runs
+    fx, fin = oracle_fixture("fullsize_mnist_%d" % nb, {"x": x[:nb], "z0": z0[:nb * R]},
+                             torch_runs(p, "mnist", R, L, 10.0, want32=False, want_rec=True))
+    assert np.array_equal(fin["x"], x[:nb]) and np.array_equal(fin["z0"], z0[:nb * R])     # (NumPy-generated inputs: exact)
+    t = {"rec": fx["rec64"].astype(np.float64), "loss": fx["l64"], "idx": fx["idx64"]}
     mse = ((out["rec"][:nb] - t["rec"]) ** 2).reshape(nb, -1).mean(axis=1)
     assert (mse < 1e-4).all(), mse
     gap = np.sort(t["loss"].reshape(nb, R), axis=1)

@@ -95,27 +95,32 @@ def test_distributional_tier_on_the_bench_inputs(workload, nb):
     out = gan.reconstruct(x, seed=2024, first_row=0, return_details=True)
     given = gan.reconstruct(x, z_init_val=z0, return_details=True)
     assert torch.equal(out["rec"], given["rec"]) and torch.equal(out["loss"], given["loss"])
-    xs, zs = x[:nb].cpu().numpy(), z0[:nb * R].cpu().numpy()
-    dev = out["loss"][:nb * R].cpu().numpy().reshape(nb, R)
-    idx = out["idx"][:nb].cpu().numpy()
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch=arch, loss_at=HORIZONS)
-    t64 = T.reconstruct(p, xs.astype(np.float64), zs.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch=arch,
-                        dtype=torch.float64, loss_at=HORIZONS)
-    l32, l64 = t32["loss"].reshape(nb, R).astype(np.float64), t64["loss"].reshape(nb, R)
+    from tests.helpers import oracle_fixture, torch_runs
+    # the torch-float32 / float64 runs of these nb images: a committed fixture (tests/helpers.py oracle_fixture), the device then
+    # runs on the fixture's exact inputs
+    fx, fin = oracle_fixture("tier_%s_%d" % (workload, nb), {"x": x[:nb].cpu().numpy(), "z0": z0[:nb * R].cpu().numpy()},
+                             torch_runs(p, arch, R, L, 10.0, HORIZONS))
+    xs = torch.from_numpy(fin["x"]).to(x.device)
+    zs = torch.from_numpy(fin["z0"]).to(x.device)
+    first = gan.reconstruct(xs, z_init_val=zs, return_details=True)
+    if np.array_equal(fin["x"], x[:nb].cpu().numpy()) and np.array_equal(fin["z0"], z0[:nb * R].cpu().numpy()):
+        assert torch.equal(first["loss"], out["loss"][:nb * R])        # rows do not depend on the batch they are in
+    dev = first["loss"].cpu().numpy().reshape(nb, R)
+    idx = first["idx"].cpu().numpy()
+    l32, l64 = fx["l32"].reshape(nb, R), fx["l64"].reshape(nb, R)
     msg, decided = distributional_tier(l32, l64, dev, idx)
     print(msg)
     # the reported reconstruction error of the BASELINE metric ("recon MSE"): MSE(rec, x) of the selected restart
-    mse_dev = ((out["rec"][:nb] - x[:nb]) ** 2).flatten(1).mean(dim=1).cpu().numpy()
+    mse_dev = ((first["rec"] - xs) ** 2).flatten(1).mean(dim=1).cpu().numpy()
     np.testing.assert_allclose(mse_dev, dev.min(axis=1), rtol=2e-4)
     # ---- selection at the shorter horizons, same lr
     fracs = {L: float(decided.mean())}
     agreement = {}
     for Lh in HORIZONS:
         gan.rec_iters = Lh
-        o = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
+        o = gan.reconstruct(xs, z_init_val=zs, return_details=True)
         ld = o["loss"].cpu().numpy().reshape(nb, R).astype(np.float64)
-        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        h32, h64 = fx["l32_at_%d" % Lh].reshape(nb, R), fx["l64_at_%d" % Lh].reshape(nb, R)
         dec = decidable(h32, h64)
         fracs[Lh] = float(dec.mean())
         sel = o["idx"].cpu().numpy()
@@ -155,30 +160,31 @@ def test_celeba_clean_targets_at_the_reference_lr_up_to_the_longest_decidable_ho
     gan, p = make_gan(arch, wseed=1234, gain=2.0, bias_range=0.0, rec_rr=R, rec_iters=L, rec_lr=10.0)
     x = gan.generate(gan.init_latents(B, seed=1000, first_row=0)).contiguous()           # clean targets, keyed by the image index
     z0 = gan.init_latents(B * R, seed=2024, first_row=0)
-    xs, zs = x[:nb].cpu().numpy(), z0[:nb * R].cpu().numpy()
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t32 = T.reconstruct(p, xs, zs, R, L, lr=10.0, momentum=0.7, arch=arch, loss_at=horizons)
-    t64 = T.reconstruct(p, xs.astype(np.float64), zs.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch=arch,
-                        dtype=torch.float64, loss_at=horizons)
+    from tests.helpers import oracle_fixture, torch_runs
+    fx, fin = oracle_fixture("celeba_clean_%d" % nb, {"x": x[:nb].cpu().numpy(), "z0": z0[:nb * R].cpu().numpy()},
+                             torch_runs(p, arch, R, L, 10.0, horizons))
+    xs = torch.from_numpy(fin["x"]).to(x.device)
+    zs = torch.from_numpy(fin["z0"]).to(x.device)
+    at = lambda Lh: (fx["l32_at_%d" % Lh].reshape(nb, R), fx["l64_at_%d" % Lh].reshape(nb, R))
     frac = {}
     for Lh in horizons:
-        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        h32, h64 = at(Lh)
         frac[Lh] = float(decidable(h32, h64).mean())
     usable = [Lh for Lh in horizons if frac[Lh] >= 0.5]
     print("decidable fraction by horizon (clean CelebA targets, lr = 10): %s" % frac)
     assert usable and max(usable) >= 10, frac
     for Lh in sorted(set([usable[0], max(usable)])):
         gan.rec_iters = Lh
-        o = gan.reconstruct(x[:nb], z_init_val=z0[:nb * R], return_details=True)
+        o = gan.reconstruct(xs, z_init_val=zs, return_details=True)
         ld = o["loss"].cpu().numpy().reshape(nb, R).astype(np.float64)
-        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        h32, h64 = at(Lh)
         dec = decidable(h32, h64)
         sel = o["idx"].cpu().numpy()
         assert (sel[dec] == h64.argmin(axis=1)[dec]).all(), (Lh, sel, h64.argmin(axis=1), dec)
         tol = 3.0 * np.abs(h32 - h64).max() + 4e-6 * np.abs(h64)
         assert (np.abs(ld - h64) <= tol).mean() >= 0.9, (Lh, np.abs(ld - h64).max(), np.abs(h32 - h64).max())
         # the selected reconstruction's error is the loss the call reports
-        mse = ((o["rec"] - x[:nb]) ** 2).flatten(1).mean(dim=1).cpu().numpy()
+        mse = ((o["rec"] - xs) ** 2).flatten(1).mean(dim=1).cpu().numpy()
         np.testing.assert_allclose(mse, ld.min(axis=1), rtol=2e-4, atol=1e-9)
     print("longest decidable horizon: L = %d (%.0f %% of %d images)" % (max(usable), 100 * frac[max(usable)], nb))
 
@@ -198,13 +204,13 @@ def test_mnist_family_clean_targets_at_the_reference_lr_up_to_the_longest_decida
     gan, p = make_gan(arch, wseed=wseed, gain=gain, bias_range=0.0, rec_rr=R, rec_iters=L, rec_lr=10.0)
     x, _ = clean_targets(p, "mnist", nb, seed=1000)
     z0 = synth.make_z(nb * R, 128, seed=2024)
-    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
-    t32 = T.reconstruct(p, x, z0, R, L, lr=10.0, momentum=0.7, arch="mnist", loss_at=horizons)
-    t64 = T.reconstruct(p, x.astype(np.float64), z0.astype(np.float64), R, L, lr=10.0, momentum=0.7, arch="mnist",
-                        dtype=torch.float64, loss_at=horizons)
+    from tests.helpers import oracle_fixture, torch_runs
+    fx, fin = oracle_fixture("%s_gain%d_clean_%d" % (arch, int(gain), nb), {"x": x, "z0": z0}, torch_runs(p, "mnist", R, L, 10.0, horizons))
+    x, z0 = fin["x"], fin["z0"]
+    at = lambda Lh: (fx["l32_at_%d" % Lh].reshape(nb, R), fx["l64_at_%d" % Lh].reshape(nb, R))
     frac = {}
     for Lh in horizons:
-        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        h32, h64 = at(Lh)
         frac[Lh] = float(decidable(h32, h64).mean())
     usable = [Lh for Lh in horizons if frac[Lh] >= 0.5]
     print("decidable fraction by horizon (%s weights, gain %.1f, clean targets, lr = 10): %s" % (arch, gain, frac))
@@ -213,7 +219,7 @@ def test_mnist_family_clean_targets_at_the_reference_lr_up_to_the_longest_decida
         gan.rec_iters = Lh
         o = gan.reconstruct(x, z_init_val=z0, return_details=True)
         ld = np.asarray(o["loss"]).reshape(nb, R).astype(np.float64)
-        h32, h64 = t32["loss_at"][Lh].reshape(nb, R).astype(np.float64), t64["loss_at"][Lh].reshape(nb, R)
+        h32, h64 = at(Lh)
         dec = decidable(h32, h64)
         sel = np.asarray(o["idx"])
         # (as in the distributional tier: "decidable" is judged by torch-float32's deviations, another float32 summation order
