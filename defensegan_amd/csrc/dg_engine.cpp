@@ -167,15 +167,6 @@ struct dg_handle {
     // 0 = the position-batched kernel as for every other layer.  Bit-identical either way (same fma chains, same K slices).
     int latent_turn = 1;
     int update_fold = 0;           // momentum update folded into the Linear backward launch (dg_linear.hip); needs latent_turn
-    // "Update overlap" (round 6, default on): the Linear forward that follows a momentum update is enqueued WITHOUT the queue's
-    // barrier bit (hipExtAnyOrderLaunch), so its workgroups start beside the update's and fetch their 64 KB of stationary weights --
-    // 4-5 us during which the launch used to wait for the 6.7-us update to drain; each then waits for the update's arrival counter
-    // before it stages z (momentum_update_kernel<true>, lin_stationary_kernel `waiting`).  Bit-identical results.
-    int update_overlap = 1;
-    unsigned* upd_done = nullptr;  // the counter: advanced by the update's workgroup count per signalling launch, never reset
-    unsigned upd_done_host = 0;    // what the counter will read once every update enqueued so far has finished (wraps with it)
-    bool f1_waits = false;         // the next Linear forward of the loop follows a signalling update
-    bool overlap_now = false;      // this call runs the update overlap (dg_reconstruct: not under stream capture, one row group)
     unsigned* upd_count = nullptr; // one arrival counter per 32-row block (+ one per row group), zero between launches
     int lin_groups_fwd = 0, lin_groups_bwd = 0;   // workgroups per column tile / K slice; 0 = pick from the CU count
     int cu_count = 256;
@@ -1030,13 +1021,6 @@ int run_lin_stationary(dg_handle* h, GemmOp& op, const float* A, float* Out, int
     a.out_frag = fwd ? out_frag : nullptr;
     a.gate_bits = fwd ? gates : nullptr;
     a.gate_words = h->lin_out / 32;
-    a.wait_count = nullptr; a.wait_target = 0u; a.any_order = 0;
-    if (fwd && h->f1_waits && !prof) {                 // update overlap: beside the momentum update enqueued just before
-        a.wait_count = h->upd_done;
-        a.wait_target = h->upd_done_host;
-        a.any_order = 1;
-    }
-    if (fwd) h->f1_waits = false;
     a.upd_z = nullptr; a.upd_m = nullptr; a.upd_count = nullptr; a.upd_lr = 0.f; a.upd_momentum = 0.f;
     if (uf && !fwd) { a.upd_z = uf->z; a.upd_m = uf->m; a.upd_count = uf->count; a.upd_lr = uf->lr; a.upd_momentum = uf->momentum; }
     a.A = A;
@@ -1391,15 +1375,8 @@ int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float mo
             rc = run_backward(h, g, prof);
             if (rc) return rc;
             ProfScope ps(h, g.s, prof, "UPD@momentum_update_kernel", 0.0);
-            // update overlap: the next step's Linear forward starts beside this launch and waits for its arrival counter (not in a
-            // profiled step -- the markers between the launches serialise them anyway -- and not for the step whose forward is
-            // profiled)
-            const bool next_prof = h->prof_stride > 0 && ((k + 1) % h->prof_stride) == 0;
-            const bool signal = h->overlap_now && ngroups == 1 && !prof && !next_prof && lin_stationary(h, h->F1);
-            unsigned grid = 0;
             dg::launch_momentum_update(h->z + r0 * h->latent, h->m + r0 * h->latent, h->part + r0 * h->nsplit * h->latent,
-                                       h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s, signal ? h->upd_done : nullptr, &grid);
-            if (signal) { h->upd_done_host += grid; h->f1_waits = true; }
+                                       h->nsplit, g.n_rows, h->latent, lr_k, momentum, nullptr, g.s);
         }
     }
     return DG_OK;
@@ -1532,8 +1509,6 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
         dmalloc(&h->bias[d], h->dec[d].cout);
     }
     if (e == hipSuccess) e = hipMemset(h->xzero, 0, (size_t)h->P * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&h->upd_done, 256);
-    if (e == hipSuccess) e = hipMemset(h->upd_done, 0, 256);
     if (e != hipSuccess) { dg_destroy(h); return fail(DG_E_NOMEM, "hipMalloc(weights): %s", hipGetErrorString(e)); }
     bool ok = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < dg_handle::kMaxGroups - 1; ++i)
@@ -1566,7 +1541,6 @@ int dg_destroy(dg_handle* h) {
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     for (auto& a : h->ai) { fr(a.scale); fr(a.offset); fr(a.fstats); fr(a.bstats); }
     fr(h->lin_w); fr(h->lin_wt); fr(h->lin_b); fr(h->lin_pack_fwd); fr(h->lin_pack_bwd); fr(h->xzero); fr(h->tail_pack); fr(h->tail_pack16);
-    if (h->upd_done) (void)hipFree(h->upd_done);
     if (h->d_tail_trace) (void)hipFree(h->d_tail_trace);
     if (h->d_job_trace) (void)hipFree(h->d_job_trace);
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i) {
@@ -1777,19 +1751,6 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = h->side_stream[gi - 1];
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
-    }
-    // update overlap (dg_handle::update_overlap): only on the eager path of an uncaptured stream (a captured hipExtLaunchKernel
-    // would lose its flag at best); the counter restarts with every call, so that a call that died cannot leave the tally off
-    {
-        hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing(s, &cap0) != hipSuccess || cap0 != hipStreamCaptureStatusNone;
-        if (capturing) (void)hipGetLastError();
-        h->overlap_now = h->update_overlap && !capturing && ngroups == 1 && !update_folds(h) && !(h->graph_max_rows > 0 && n_rows <= h->graph_max_rows);
-        h->f1_waits = false;
-        if (h->overlap_now) {
-            HIP_TRY(hipMemsetAsync(h->upd_done, 0, sizeof(unsigned), s));
-            h->upd_done_host = 0;
-        }
     }
     // Small prepared shapes replay a captured graph of the loop instead of enqueuing its ~8 L launches one by one
     bool replayed = false;
@@ -2076,12 +2037,6 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         h->graph_broken = false;
         drop_graphs(h);
         free_workspace(h);               // the staging copy of the images is sized by this option
-        return DG_OK;
-    }
-    if (k == "update_overlap") {         // 1 = the Linear forward starts beside the momentum update that feeds it (default), 0 = in order
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->update_overlap = atoi(value) != 0;
         return DG_OK;
     }
     if (k == "update_fold") {            // 1 = the momentum update rides in the Linear backward launch (needs latent_turn)

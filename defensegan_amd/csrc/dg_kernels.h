@@ -137,12 +137,6 @@ struct LinArgs {
     // backward only, optional: the momentum update folded into this launch (dg_linear.hip, "folded update").  The workgroup
     // that stores the LAST of a 32-row block's `units` K slices sums the slices in slice order and applies ApplyMomentum to
     // upd_z / upd_m (both [n_rows][128], the rows of Out); upd_count = one arrival counter per 32-row block, zero between launches
-    // forward only, optional ("update overlap", dg_engine.cpp): this launch was enqueued without the queue's barrier bit behind the
-    // momentum update; every workgroup loads its weights, then waits until *wait_count has reached wait_target (wrap-safe compare)
-    // before it touches A (= z).  any_order = launch without the barrier bit (hipExtAnyOrderLaunch).
-    const unsigned* wait_count;
-    unsigned wait_target;
-    int any_order;
     // forward only, optional: the output in FRAGMENT ORDER (dg_types.h; rows padded to a multiple of 32) instead of Out, and the
     // ReluGrad gates as one bit per element ([rows][gate_words] words, bit f % 32 of word f / 32)
     float* out_frag;
@@ -222,11 +216,8 @@ void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, 
 
 // ---- small kernels ----------------------------------------------------------------------------
 // m = momentum*m + sum_s part[n][s][:];  z -= lr*m     (ApplyMomentum, gan.py:389-391)
-// done != nullptr: every workgroup adds 1 to *done once its z values are visible device-wide (sc1 stores, drained); *grid_out = the
-// number of workgroups launched (what *done advances by).  See momentum_update_kernel.
 void launch_momentum_update(float* z, float* m, const float* part, int nsplit, int64_t n_elems_rows,
-                            int latent, float lr, float momentum, float* dz_out, hipStream_t s, unsigned* done = nullptr,
-                            unsigned* grid_out = nullptr);
+                            int latent, float lr, float momentum, float* dz_out, hipStream_t s);
 // first-argmin over R restarts + gather (gan.py:438-449)
 void launch_select(const float* loss, const float* y, int B, int R, int P, float* out_rec, int32_t* out_idx,
                    hipStream_t s);

@@ -17,8 +17,6 @@
 // row is in.  The backward keeps the engine's fixed K slices: slice sums are still added in slice order by the update.
 // Optional (engine option update_fold, off: measured slower, profiles/r04_ab_update_fold.txt): the update itself inside the backward
 // launch, done by the workgroup that delivers a row block's last slice ("folded update" below).
-#include <hip/hip_ext.h>
-
 #include "dg_kernels.h"
 
 namespace dg {
@@ -81,13 +79,8 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
         for (int c = 0; c < KCH; ++c)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, DG_LDS_PTR(dst + c * 4096 + wave * 1024), 16, voff, c * 128, 0, 0);
     };
-    // "update overlap" (forward only): this launch may run beside the momentum update that produces its A operand; then the
-    // weights -- which depend on nobody -- are fetched first, and A is staged once the update has signalled completion
-    const bool waiting = MODE != EPI_STORE && g.wait_count != nullptr;
-    if (!waiting) {
-        stage(grp, smem);
-        if (n_my > 1) stage(grp + g.groups, smem + BLK_BYTES);   // both buffers are free: the second block rides with the weights
-    }
+    stage(grp, smem);
+    if (n_my > 1) stage(grp + g.groups, smem + BLK_BYTES);       // both buffers are free: the second block rides with the weights
 
     // ---- stationary operand: this wave's 32 output columns x K, as MFMA B fragments (lane = column + 32 * k-half)
     f32x4 wf[KCH][4];
@@ -97,18 +90,6 @@ __global__ __launch_bounds__(256, KCH <= 4 ? 3 : (KCH <= 6 ? 2 : 1)) void lin_st
         for (int c = 0; c < KCH; ++c)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) wf[c][kk] = *reinterpret_cast<const f32x4*>(wp + (c * 4 + kk) * 256);
-    }
-    if (waiting) {
-        // one lane polls (relaxed agent-scope loads: never this CU's L1); the barrier also lands every wave's weights.  Wrap-safe:
-        // the counter only grows, by the update's workgroup count per launch
-        // (bounded: a lost update launch must not hang the device -- ~0.3 s, then the results are wrong and the caller's error
-        // check of that launch has long fired)
-        if (tid == 0)
-            for (int spin = 0; spin < 300000 && (int)(__hip_atomic_load(g.wait_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - g.wait_target) < 0; ++spin)
-                __builtin_amdgcn_s_sleep(4);
-        __syncthreads();
-        stage(grp, smem);
-        if (n_my > 1) stage(grp + g.groups, smem + BLK_BYTES);
     }
     const int er = lane >> 3, ec = (lane & 7) * 4;
     const int ocol = unit * g.out_unit + wave * 32 + ec;
@@ -359,11 +340,7 @@ void launch_km(const LinArgs& a, hipStream_t s) {
     if (attr.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lin_stationary_kernel<KCH, MODE, FOLD, FRAG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (a.any_order && MODE != EPI_STORE)
-        hipExtLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD, FRAG>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, nullptr, nullptr,
-                              hipExtAnyOrderLaunch, a);
-    else
-        hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD, FRAG>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((lin_stationary_kernel<KCH, MODE, FOLD, FRAG>), dim3((unsigned)(a.units * a.groups)), dim3(256), lds, s, a);
 }
 
 template <int KCH>

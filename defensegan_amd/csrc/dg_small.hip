@@ -8,78 +8,44 @@ namespace dg {
 //   m <- momentum*m + g ;  z <- z - lr*m
 // One thread owns 4 consecutive latent components of one row; the partials of up to 8 slices are fetched before the first add
 // (the adds keep the slice order: bit-identical for any nsplit grouping).
-// SIGNAL: the launch that follows (the Linear forward, dg_linear.hip) was enqueued WITHOUT the queue's barrier bit and loads its
-// 64 KB of stationary weights per workgroup while this kernel runs (dg_engine.cpp "update overlap"); it reads z only after every
-// workgroup here has arrived at `done`.  For that hand-off z is read with sc1 loads (not through this CU's vector L1, where the
-// OTHER launch's reads of the same CU would find the old line) and written with sc1 stores (write-through, the line leaves this
-// XCD's L2), every wave drains its stores, barrier, one relaxed agent-scope increment per workgroup -- the recipe of the K-pair
-// hand-off in dg_gemm.hip.  Same arithmetic, same results.
-template <bool SIGNAL>
 __global__ __launch_bounds__(256) void momentum_update_kernel(float* __restrict__ z, float* __restrict__ m,
                                                               const float* __restrict__ part, int nsplit,
                                                               long long n_quads, int latent, float lr,
-                                                              float momentum, float* __restrict__ dz_out, unsigned* done) {
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                                                              float momentum, float* __restrict__ dz_out) {
     const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (q < n_quads) {
-        const unsigned qrow = (unsigned)latent >> 2;
-        const long long n = q / qrow;
-        const int d = (int)(q - n * qrow) << 2;
-        const float* p = part + n * (long long)nsplit * latent + d;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int s0 = 0; s0 < nsplit; s0 += 8) {
-            float4 v[8];
+    if (q >= n_quads) return;
+    const unsigned qrow = (unsigned)latent >> 2;
+    const long long n = q / qrow;
+    const int d = (int)(q - n * qrow) << 2;
+    const float* p = part + n * (long long)nsplit * latent + d;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < nsplit; s0 += 8) {
+        float4 v[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s0 + s < nsplit) v[s] = *reinterpret_cast<const float4*>(p + (long long)(s0 + s) * latent);
+        for (int s = 0; s < 8; ++s)
+            if (s0 + s < nsplit) v[s] = *reinterpret_cast<const float4*>(p + (long long)(s0 + s) * latent);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s0 + s < nsplit) { g.x += v[s].x; g.y += v[s].y; g.z += v[s].z; g.w += v[s].w; }
-        }
-        const long long i = n * latent + d;
-        if (dz_out) { dz_out[i] = g.x; dz_out[i + 1] = g.y; dz_out[i + 2] = g.z; dz_out[i + 3] = g.w; return; }   // caller's pointer: no alignment assumed
-        const float4 m0 = *reinterpret_cast<const float4*>(m + i);
-        float4 z0;
-        // (descriptor at this workgroup's first quad: the per-lane offset stays below 4 KB whatever the row count)
-        float* zblk = z + (long long)blockIdx.x * 1024;
-        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zblk, 0, 0x7ffffff0, 0x00020000);
-        if constexpr (SIGNAL) {
-            const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr, (int)threadIdx.x * 16, 0, 16));
-            z0 = make_float4(t[0], t[1], t[2], t[3]);
-        } else {
-            z0 = *reinterpret_cast<const float4*>(z + i);
-        }
-        float4 mm, zz;
-        mm.x = momentum * m0.x + g.x; mm.y = momentum * m0.y + g.y; mm.z = momentum * m0.z + g.z; mm.w = momentum * m0.w + g.w;
-        zz.x = z0.x - lr * mm.x; zz.y = z0.y - lr * mm.y; zz.z = z0.z - lr * mm.z; zz.w = z0.w - lr * mm.w;
-        *reinterpret_cast<float4*>(m + i) = mm;
-        if constexpr (SIGNAL) {
-            const f32x4 t = {zz.x, zz.y, zz.z, zz.w};
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), zr, (int)threadIdx.x * 16, 0, 16);
-        } else {
-            *reinterpret_cast<float4*>(z + i) = zz;
-        }
+        for (int s = 0; s < 8; ++s)
+            if (s0 + s < nsplit) { g.x += v[s].x; g.y += v[s].y; g.z += v[s].z; g.w += v[s].w; }
     }
-    if constexpr (SIGNAL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const long long i = n * latent + d;
+    if (dz_out) { dz_out[i] = g.x; dz_out[i + 1] = g.y; dz_out[i + 2] = g.z; dz_out[i + 3] = g.w; return; }   // caller's pointer: no alignment assumed
+    const float4 m0 = *reinterpret_cast<const float4*>(m + i);
+    const float4 z0 = *reinterpret_cast<const float4*>(z + i);
+    float4 mm, zz;
+    mm.x = momentum * m0.x + g.x; mm.y = momentum * m0.y + g.y; mm.z = momentum * m0.z + g.z; mm.w = momentum * m0.w + g.w;
+    zz.x = z0.x - lr * mm.x; zz.y = z0.y - lr * mm.y; zz.z = z0.z - lr * mm.z; zz.w = z0.w - lr * mm.w;
+    *reinterpret_cast<float4*>(m + i) = mm;
+    *reinterpret_cast<float4*>(z + i) = zz;
 }
 
 void launch_momentum_update(float* z, float* m, const float* part, int nsplit, int64_t n_rows, int latent,
-                            float lr, float momentum, float* dz_out, hipStream_t s, unsigned* done, unsigned* grid_out) {
+                            float lr, float momentum, float* dz_out, hipStream_t s) {
     const long long n_quads = (long long)n_rows * (latent >> 2);          // latent % 64 == 0 (dg_create)
-    if (grid_out) *grid_out = 0;
     if (n_quads == 0) return;
     const unsigned grid = (unsigned)((n_quads + 255) / 256);
-    if (grid_out) *grid_out = grid;
-    if (done && !dz_out)
-        hipLaunchKernelGGL(momentum_update_kernel<true>, dim3(grid), dim3(256), 0, s, z, m, part, nsplit, n_quads, latent, lr, momentum, dz_out, done);
-    else
-        hipLaunchKernelGGL(momentum_update_kernel<false>, dim3(grid), dim3(256), 0, s, z, m, part, nsplit, n_quads, latent, lr, momentum, dz_out,
-                           (unsigned*)nullptr);
+    hipLaunchKernelGGL(momentum_update_kernel, dim3(grid), dim3(256), 0, s, z, m, part, nsplit, n_quads, latent, lr,
+                       momentum, dz_out);
 }
 
 // ---- selection: first argmin over the R restarts of each image, then gather (gan.py:438-449) ------
