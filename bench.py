@@ -136,59 +136,90 @@ def physical_cores_one_socket():
         return None, ncpu
 
 
-# steps of a thread-count probe: 2-step probes preferred 64 threads on a box where the full-L run is twice as fast on 32 (their
-# three passes are dominated by the thread pool's start-up, not by the convolutions)
-PROBE_STEPS = 6
+# The ONE thread count of the CPU baseline.  Rounds 4 / 5 probed {8, 16, 32, 64, cores of a socket} and kept the fastest: the probe
+# flipped between 16, 32 and 64 from box to box (6.1 ... 8.5 images/s for one CPU model), so the reported figure meant a different
+# thing every time.  The rule is now fixed: 16 threads -- where this workload (160 MFLOP per image-step in 5x5 convolutions over
+# 16 x R rows) stops scaling on the pool's EPYC 9575F hosts: 8.5 images/s at 16, 4-6 at 32, 2.1 at 64 = the physical cores of a
+# socket (profiles/r05_bench_*; more threads lose to the thread pool's synchronisation per small convolution) -- pinned to 16
+# distinct physical cores of socket 0, two timed full-L batches, the faster one reported with the spread.
+CPU_BASELINE_THREADS = 16
+
+
+def socket0_core_cpus():
+    """Logical CPU ids, one per distinct physical core of socket 0, in /proc/cpuinfo order ([] when it cannot be read)."""
+    try:
+        out, seen, cur = [], set(), {}
+        with open("/proc/cpuinfo") as fh:
+            for line in list(fh) + ["\n"]:
+                k, _, v = line.partition(":")
+                k = k.strip()
+                if k in ("processor", "physical id", "core id"):
+                    cur[k] = v.strip()
+                elif not k and cur:
+                    if cur.get("physical id", "0") == "0" and cur.get("core id") not in seen and "processor" in cur:
+                        seen.add(cur.get("core id"))
+                        out.append(int(cur["processor"]))
+                    cur = {}
+        return out
+    except (OSError, ValueError):
+        return []
 
 
 def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
     """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed here) on this box's host
-    cores.  Thread count: the best of {8, 16, 32, 64, physical cores of one socket} on 6-step probes, each probe the FASTEST of
-    three repeats (round 4 probed once per count and saw 2.6 ... 5.3 images/s for the same batch on three boxes of one CPU
-    model: a single noisy probe picked the count).  Then TWO batches of 16 images run the FULL L steps at that count -- measured,
-    not a short sample scaled by (2L-1) -- `value` is the faster one, `spread` = (slower - faster) / faster, both times are in
-    `sample`; if the probe predicts more than `budget_s` seconds per batch it shrinks to 8 / 4 images before the step count does."""
+    cores, by a FIXED rule (CPU_BASELINE_THREADS): 16 threads pinned to 16 distinct physical cores of socket 0, one warm-up of two
+    steps, then TWO batches of 16 images over the FULL L steps -- measured, not a short sample scaled by (2L-1); `value` is the
+    faster one, `spread` = (slower - faster) / faster, both times are in `sample`.  If the warm-up predicts more than `budget_s`
+    seconds per batch the batch shrinks to 8 / 4 images before the step count does."""
     from oracle import torch_ref as T          # checker / baseline only -- never on the product path
     phys, ncpu = physical_cores_one_socket()
+    threads = max(1, min(CPU_BASELINE_THREADS, phys or ncpu, ncpu))
+    cpus = socket0_core_cpus()[:threads]
+    old_aff = None
+    try:
+        if len(cpus) == threads and hasattr(os, "sched_setaffinity"):
+            old_aff = os.sched_getaffinity(0)
+            allowed = [c for c in cpus if c in old_aff]
+            if len(allowed) == threads:
+                os.sched_setaffinity(0, allowed)
+            else:
+                old_aff = None
+    except OSError:
+        old_aff = None
+    pinned = old_aff is not None
+    torch.set_num_threads(threads)
     gen = T.TorchGenerator(params, arch)
     a = archs.make_arch(arch)
     nimg = min(16, len(x_np))
     z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
-    best = None
-    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64, phys or 64)}):
-        torch.set_num_threads(th)
-        T.reconstruct(params, x_np[:nimg], z0, R, 1, arch=arch, gen=gen)      # warm-up
-        probe = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            T.reconstruct(params, x_np[:nimg], z0, R, PROBE_STEPS, arch=arch, gen=gen)
-            dtp = time.perf_counter() - t0
-            probe = dtp if probe is None else min(probe, dtp)
-            if dtp > 10:
-                break
-        if best is None or probe < best[0]:
-            best = (probe, th)
-        if probe > 20:
-            break
-    probe, threads = best
-    torch.set_num_threads(threads)
-    per_pass = probe / (2.0 * PROBE_STEPS - 1.0)   # L steps = 2L - 1 passes over nimg images
-    Ls, n_run = L, nimg
-    while n_run > 4 and per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
-        n_run //= 2
-    if per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
-        Ls = int(max(3, (budget_s / (per_pass * n_run / float(nimg)) + 1) // 2))
-    times = []
-    for _ in range(2):
+    try:
+        T.reconstruct(params, x_np[:nimg], z0, R, 1, arch=arch, gen=gen)      # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
-        T.reconstruct(params, x_np[:n_run], z0[:n_run * R], R, Ls, arch=arch, gen=gen)
-        times.append(time.perf_counter() - t0)
+        T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
+        per_pass = (time.perf_counter() - t0) / 3.0                            # L steps = 2L - 1 passes over nimg images
+        Ls, n_run = L, nimg
+        while n_run > 4 and per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
+            n_run //= 2
+        if per_pass * (n_run / float(nimg)) * (2 * L - 1) > budget_s:
+            Ls = int(max(3, (budget_s / (per_pass * n_run / float(nimg)) + 1) // 2))
+        times = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            T.reconstruct(params, x_np[:n_run], z0[:n_run * R], R, Ls, arch=arch, gen=gen)
+            times.append(time.perf_counter() - t0)
+    finally:
+        if old_aff is not None:
+            try:
+                os.sched_setaffinity(0, old_aff)
+            except OSError:
+                pass
     dt = min(times)
     t_full = dt * (2 * L - 1) / (2 * Ls - 1)                                  # == dt when the full L ran
-    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads (best of 6-step probes, 3 repeats each) of %d host CPUs (%s physical cores on socket 0), two batches %.1f s and %.1f s, the faster one reported%s" % (
-        n_run, R, Ls, threads, ncpu, phys if phys else "?", times[0], times[1], "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
+    sample = "%d images x R=%d x L=%d, torch-CPU autograd restatement, %d threads (fixed rule)%s of %d host CPUs (%s physical cores on socket 0), two batches %.1f s and %.1f s, the faster one reported%s" % (
+        n_run, R, Ls, threads, " pinned to %d cores of socket 0" % threads if pinned else "", ncpu, phys if phys else "?", times[0], times[1],
+        "" if Ls == L else ", scaled by (2L-1) to L=%d" % L)
     return {"value": n_run / t_full, "unit": "images/s", "cores": threads, "threads": threads, "host_cores": ncpu,
-            "physical_cores_socket0": phys, "spread": round((max(times) - dt) / dt, 4),
+            "physical_cores_socket0": phys, "pinned": pinned, "spread": round((max(times) - dt) / dt, 4),
             "cpu_model": _cpu_model(), "kind": "port", "sample": sample}
 
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 // 16 sums are folded in LDS in a fixed order.
 template <typename PartT>          // double: bn_partial_kernel's sums; float: the GEMM epilogue's per-32-row-block sums (EPI_BIAS_STATS)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const PartT* __restrict__ part, int nblk, long long rows, int C,
-                                                          float* __restrict__ stats, int forward) {
+                                                          float* __restrict__ stats, int forward, const float* __restrict__ shift = nullptr) {
     __shared__ double red[2][256];
     const int tid = threadIdx.x;
     const int cl = tid & 15, j = tid >> 4;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const PartT* __restric
     if (forward) {
         double var = m2 - m1 * m1;
         if (var < 0.0) var = 0.0;
-        stats[c] = (float)m1;
+        // (block sums of the GEMM epilogue are taken before the bias: shift[c] puts it back; the variance does not see it)
+        stats[c] = (float)(m1 + (shift ? (double)shift[c] : 0.0));
         stats[C + c] = (float)(1.0 / sqrt(var + 1e-5));
     } else {
         stats[c] = (float)m1;
@@ -244,12 +245,13 @@ __global__ __launch_bounds__(256) void bn_fold_blocks_kernel(const float* __rest
     }
 }
 
-void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s) {
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift) {
     const int per_range = (nblk + BN_FOLD_RANGES - 1) / BN_FOLD_RANGES;
     const int ranges = (nblk + per_range - 1) / per_range;
     const int quads = (2 * a.C) / 4;
     hipLaunchKernelGGL(bn_fold_blocks_kernel, dim3((unsigned)ranges, (unsigned)((quads + 255) / 256)), dim3(256), 0, s, block_sums, a.part, nblk, a.C, per_range);
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1);
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1,
+                       shift);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);

@@ -69,6 +69,7 @@ struct ActInfo {
     float* fstats = nullptr;  // [2, bn_C]
     float* bstats = nullptr;  // [2, bn_C]
     float* block_sums = nullptr;  // [blocks][2][bn_C]: per-32-row-block column sums left by the producing GEMM's epilogue (EPI_BIAS_STATS)
+    int64_t block_cap = 0;        // blocks block_sums holds
 };
 
 // Job list of a position-batched launch (dg_gemm.hip), one per row count a layer has been run with.
@@ -111,6 +112,7 @@ struct GemmOp {
     const float* W = nullptr;
     const float* bias = nullptr;
     float* stats = nullptr;   // EPI_BIAS_STATS: the block sums of the activation this layer produces (ActInfo::block_sums)
+    int64_t stats_cap = 0;    // blocks that buffer holds
 };
 
 constexpr int kJobTraceCap = 65536;
@@ -210,7 +212,7 @@ struct dg_handle {
     int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
                                    // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
-    int tail_pipe_version = 3;     // mnist_tail_pipe3_kernel / _pipe2_ / _pipe_kernel (dg_tail_mfma.hip)
+    int tail_pipe_version = 3;     // mnist_tail_pipe3_kernel / _pipe2_ / _pipe_kernel (dg_tail_mnist.hip)
     long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
     // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
     // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
@@ -455,7 +457,7 @@ void free_workspace(dg_handle* h) {
     for (auto& a : h->act) fr(a);
     for (auto& a : h->actf) fr(a);
     for (auto& g : h->gate) if (g) { (void)hipFree(g); g = nullptr; }
-    for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); fr(a.block_sums); }
+    for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); fr(a.block_sums); a.block_cap = 0; }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
     if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
     h->cap_rows = 0;
@@ -503,16 +505,21 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         a.buf = h->act[d];
         if (a.has_bn) {
             HIP_TRY(hipMalloc(&a.xhat, cap * a.row_floats * sizeof(float)));
-            // blocks: ceil(rows * positions_of_class / 32) summed over the classes <= rows * positions / 32 + one per class
-            const size_t blocks = (size_t)(cap * a.bn_rows / 32 + 128);
-            HIP_TRY(hipMalloc(&a.block_sums, blocks * 2 * (size_t)a.bn_C * sizeof(float)));
+            if (h->bn_fused) {
+                // 32-row statistics blocks of the producing GEMM at `cap` rows (dg_plan.h stat_blocks: ceil(rows * positions / 32)
+                // per tap class); bn_forward refuses a launch that would need more
+                const GemmOp& producer = d == 0 ? h->F1 : h->Fd[(size_t)d - 1];
+                const size_t blocks = (size_t)dg::stat_blocks(producer.bplan, (int)std::min<int64_t>(cap, 1 << 24));
+                HIP_TRY(hipMalloc(&a.block_sums, blocks * 2 * (size_t)a.bn_C * sizeof(float)));
+                a.block_cap = (int64_t)blocks;
+            }
             const size_t need = (size_t)dg::bn_max_blocks() * 2 * a.bn_C;
             if (need > part_doubles) part_doubles = need;
         }
     }
     if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
-    h->F1.stats = h->ai[0].block_sums;
-    for (int d = 0; d + 1 < nd; ++d) h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums;
+    h->F1.stats = h->ai[0].block_sums; h->F1.stats_cap = h->ai[0].block_cap;
+    for (int d = 0; d + 1 < nd; ++d) { h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums; h->Fd[(size_t)d].stats_cap = h->ai[d + 1].block_cap; }
     h->cap_rows = cap;
     return DG_OK;
 }
@@ -702,6 +709,11 @@ const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, fl
             c.jobs = dg::jobs_balanced(op.bplan, n_rows, op.family, cus, h->job_slots_per_cu[op.family][lvl], lvl, h->job_model);
             if (c.jobs.empty()) continue;
             c.jl.predicted_us = dg::simulate_jobs(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], h->job_model);
+            if (h->job_pair_kernel >= 2) c.jl.pair_kernel = 1;
+            if (h->job_prio >= 2) {
+                c.jl.prio = 1;
+                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], h->job_model, 1);
+            }
             cands.push_back(std::move(c));
         }
     }
@@ -1063,6 +1075,9 @@ int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, h
     if (lin_stationary(h, op)) return run_lin_stationary(h, op, A, Out, n_rows, s, prof);
     const JobList* jl = find_jobs(op, n_rows);
     if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
+    if (op.mode == dg::EPI_BIAS_STATS && (!op.stats || dg::stat_blocks(op.bplan, n_rows) > op.stats_cap))
+        return fail(DG_E_STATE, "layer %s: %lld statistics blocks at %d rows, the buffer holds %lld", op.name.c_str(),
+                    (long long)dg::stat_blocks(op.bplan, n_rows), n_rows, (long long)op.stats_cap);
     int group = 0;                                   // the row group launching: its own copy of the list's pair scratch
     for (int i = 0; i < dg_handle::kMaxGroups - 1; ++i)
         if (s == h->side_stream[i] && s != nullptr) group = i + 1;
@@ -1205,7 +1220,8 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     auto bn_forward = [&](int d, const GemmOp& producer) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
         if (producer.mode == dg::EPI_BIAS_STATS)
-            dg::launch_bn_forward_from_blocks(bn_args(h, h->ai[d], n_rows), h->ai[d].block_sums, (int)dg::stat_blocks(producer.bplan, n_rows), 1, s);
+            dg::launch_bn_forward_from_blocks(bn_args(h, h->ai[d], n_rows), h->ai[d].block_sums, (int)dg::stat_blocks(producer.bplan, n_rows), 1, s,
+                                              producer.bias);
         else
             dg::launch_bn_forward(bn_args(h, h->ai[d], n_rows), 1, s);
     };
@@ -1338,10 +1354,12 @@ int rebuild_plans(dg_handle* h) {
     const size_t ndec = h->dec.size();
     h->F1.W = h->lin_wt; h->F1.bias = h->lin_b;
     h->F1.stats = h->ai.empty() ? nullptr : h->ai[0].block_sums;
+    h->F1.stats_cap = h->ai.empty() ? 0 : h->ai[0].block_cap;
     h->B1.W = h->lin_w;
     for (size_t d = 0; d + 1 < ndec; ++d) {
         h->Fd[d].W = h->F[d]; h->Fd[d].bias = h->bias[d];
         h->Fd[d].stats = h->ai[d + 1].block_sums;
+        h->Fd[d].stats_cap = h->ai[d + 1].block_cap;
         h->Bd[d].W = h->Ft[d];
     }
     return DG_OK;
@@ -2080,6 +2098,9 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     }
     if (k == "tail_pipe_version") {
         if (atoi(value) < 1 || atoi(value) > 3) return fail(DG_E_INVALID, "tail_pipe_version: 1, 2 or 3");
+#ifndef DG_MEASURE
+        if (atoi(value) == 2) return fail(DG_E_INVALID, "tail_pipe_version = 2 (the superseded second-generation kernel) needs the measurement build");
+#endif
         h->tail_pipe_version = atoi(value);
         return DG_OK;
     }

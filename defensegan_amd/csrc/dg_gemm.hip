@@ -9,9 +9,10 @@
 //  * M axis = (latent row, output position) pairs of one tap CLASS (dg_plan.cpp): positions with the same relative tap
 //    pattern share the filter slabs, so an M tile is dense for ANY batch size and every tile of a class has the same K.
 //  * One workgroup = one JOB from a host-built list ordered longest first; the hardware dispatcher is the (dynamic) queue.
-//    Jobs late in the list are the same tiles cut in halves / quarters along M and N (never along K, so every output
-//    element keeps its summation order whatever the batch looks like): big tiles for the MFMA rate, small ones to level
-//    the end of the launch.
+//    Jobs late in the list are the same tiles cut in halves / quarters along M and N -- never along K, except for the fixed
+//    two-half split of the K-pair classes (dg_plan.h class_is_paired: a constant of the layer plan) -- so every output element
+//    keeps its summation tree whatever the batch and the list look like: big tiles for the MFMA rate, small ones to level the
+//    end of the launch.
 //  * 128x128 tiles (2x2 waves; 256x64 with 4x1 waves for the 64-column layers; 64x64 per wave, four independent accumulators): 8 operand lines staged per 64 MFMAs
 //    instead of 8 per 32; operand DMA through buffer_load ... lds with the chunk offset in an SGPR (no address VALU).
 //  * The fragment reads of k-step kk+1 are issued before the MFMAs of k-step kk and pinned there.
@@ -298,6 +299,13 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
     // workgroup from the pair's counter (the hand-off recipe of the programming guide, guideline 16 / split-K seam).  The first
     // arriver is done; the second adds the partner's image (sc1 loads: L1 bypassed) to its own accumulators -- a + b = b + a, so
     // either arrival order gives the same bits -- and runs the epilogue.  Nobody ever waits for anybody.
+    // Memory ordering, spelled out (advisor, round 5): the image leaves with sc1 (agent-scope write-through) stores; the asm
+    // s_waitcnt vmcnt(0) of EVERY wave (a "memory" clobber: the compiler moves no access across it) followed by the workgroup barrier
+    // means all of the image is acknowledged at the agent's coherence point before lane 0 issues the ticket; the ticket is an
+    // agent-scope atomic (relaxed: the ordering is carried by the waits, not by the atomic); the second arriver's loads are sc1
+    // (never this CU's L1) and are issued after its own ticket returned and a barrier.  This is the "{sc1 stores, sc1 loads}" form
+    // the programming guide lists as valid on gfx950 without buffer_wbl2 / buffer_inv (each of which costs 1.7-6.5 us per use here).
+    // tests/test_gpu_variants.py repeats a paired launch sequence bit for bit, also with poisoned counters.
     // (compiled only into the PAIR instantiations, which run the lists that hold such jobs: with this block present hipcc allocates
     // and schedules the main loop of EVERY instantiation differently -- Generator.3's forward, which has no pair, lost 1 % to it)
     if constexpr (PAIR) if (jb.pair_id != 0) {
@@ -358,6 +366,12 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                 f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    // EPI_BIAS_STATS: the sums are taken of the accumulator BEFORE the bias (launch_bn_forward_from_blocks adds it back to
+                    // the mean in float64): the float32 block sums of x and x^2 then carry no bias-sized offset, which
+                    // E[x^2] - mean^2 would have to cancel
+                    if constexpr (MODE == EPI_BIAS_STATS) {
+                        if (ovalid[i][p]) { s1[q] += v[q]; s2[q] = __builtin_fmaf(v[q], v[q], s2[q]); }
+                    }
                     float t = v[q] + bv[q];
                     if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
                     if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
@@ -365,12 +379,6 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                     v[q] = t;
                 }
                 if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
-                if constexpr (MODE == EPI_BIAS_STATS) {
-                    if (ovalid[i][p]) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { s1[q] += v[q]; s2[q] = __builtin_fmaf(v[q], v[q], s2[q]); }
-                    }
-                }
             }
             if constexpr (MODE == EPI_BIAS_STATS) {
                 // the 8 lanes that share this lane's 4 columns hold the other rows of the 32-row block (er = lane >> 3): a fixed

@@ -182,7 +182,7 @@ struct MnistTailArgs {
     long long* trace;    // optional phase cycle totals [grid][16] of the pipelined kernel (tools/tail_trace.py), or nullptr
 #endif
 };
-void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail_mfma.hip
+void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail_mnist.hip
 
 // ---- CelebA tail: Generator.6 (64 -> 3, 64x64) + tanh + loss + backward to da5 ----------------
 struct CelebaTailArgs {
@@ -210,7 +210,7 @@ struct CelebaTailArgs {
     int prio;            // wave priority per workgroup slot (see wg_priority); 0 = all equal
 #endif
 };
-void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // dg_tail_mfma.hip
+void launch_celeba_tail_fwd_mfma(const CelebaTailArgs& a, hipStream_t s);  // dg_tail_mnist.hip
 void launch_celeba_tail_bwd_mfma(const CelebaTailArgs& a, hipStream_t s);
 void launch_celeba_loss_finish(const float* loss_part, float* loss, int n_rows, int nparts, int P, hipStream_t s);   // loss = sum(parts) / P
 
@@ -246,8 +246,10 @@ struct BnArgs {
 int bn_max_blocks();        // row blocks of the partial sums, upper bound: part holds bn_max_blocks() * 2 * C doubles
 void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
 // the forward pass when the GEMM epilogue (EPI_BIAS_STATS) has left per-block column sums in `block_sums` [nblk][2][C] (float):
-// finalize (float64) + apply -- no pass over the pre-activations for the statistics
-void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s);
+// finalize (float64) + apply -- no pass over the pre-activations for the statistics.  The block sums are those of (pre - shift[c]):
+// the producing GEMM takes them before it adds its bias (shift = that bias, per column), so that the float32 sums of x and x^2
+// carry no bias-sized offset
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift);
 void launch_bn_backward(const BnArgs& a, hipStream_t s);
 
 }  // namespace dg

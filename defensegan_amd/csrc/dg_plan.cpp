@@ -636,6 +636,7 @@ std::vector<JobDesc> jobs_from_record(const BatchedPlan& p, int family, int cus,
     if (r.snake == 4) {                          // a work-balanced single-round list is built, not ordered
         std::vector<JobDesc> jb = jobs_balanced(p, r.n_rows, family, cus, slots_per_cu, r.min_level, m);
         if (predicted_us) *predicted_us = simulate_jobs(p, jb, family, cus * slots_per_cu, m);
+        if (r.prio) assign_priorities(p, jb, family, cus * slots_per_cu, m, r.prio);       // (what the record says is what is launched)
         return jb;
     }
     std::vector<JobDesc> jobs = build_jobs(p, r.n_rows, family, cus * slots_per_cu, r.slack, m, predicted_us, r.min_level);

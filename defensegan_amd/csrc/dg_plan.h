@@ -59,7 +59,7 @@ BatchedPlan make_batched(const LayerPlan& p);
 // first (the hardware dispatcher hands workgroups out in this order).  family 0: full tile 128x128, family 1: 256x64.
 // Built by simulating that dispatch (greedy list scheduling on `slots` equal servers, cost model below): jobs are taken
 // longest first, and one that would end later than `slack` x (total cost / slots) is cut in two along M (family 0's second
-// cut: along N) -- never along K -- whose pieces queue up again, down to 64x64.  slack <= 0 picks, from a fixed ladder,
+// cut: along N) -- never along K (the K-pair classes below are split in two FIXED halves, whatever the list) -- whose pieces queue up again, down to 64x64.  slack <= 0 picks, from a fixed ladder,
 // the value with the smallest simulated makespan; slack >= 1e20 never cuts.  min_level > 0 starts every tile cut to that
 // level (1 halves, 2 quarters): such a list needs less LDS and registers per workgroup, so the caller may pass more slots.
 // Classes of at least this many K chunks (with at least two taps) are computed by K-pair jobs (dg_types.h JobDesc::pair_id):

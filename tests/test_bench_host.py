@@ -265,3 +265,19 @@ def test_dominant_symbol_is_the_one_with_the_most_flop_ties_go_to_the_forward_la
         assert abs(r["achieved"] - 200 * 4.29e10 / (f3 * 1e-3) / 1e12) < 0.01
     _, r = bench.roofline_from_profile(prof(62.0, 62.0, n_b=200), "mnist", 256, 10, 133.0, None)      # exact tie -> forward
     assert r["layers"] == ["F3"]
+
+
+def test_cpu_baseline_follows_the_fixed_rule():
+    """`cpu_baseline`: a fixed thread count (CPU_BASELINE_THREADS, capped by the box), two timed batches, the faster one and the
+    spread -- run here at a toy size (4 images, R = 2, L = 2) so that the CPU suite stays short."""
+    import numpy as np
+    from defensegan_amd import synth
+    p = synth.make_weights("mnist", seed=1234, gain=2.0, bias_range=0.0)
+    x = np.random.RandomState(0).uniform(0, 1, size=(4, 28, 28, 1)).astype(np.float32)
+    old = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    r = bench.cpu_baseline("mnist", p, x, R=2, L=2)
+    assert r["kind"] == "port" and r["unit"] == "images/s" and r["value"] > 0
+    assert r["threads"] == r["cores"] == min(bench.CPU_BASELINE_THREADS, os.cpu_count(), bench.physical_cores_one_socket()[0] or os.cpu_count())
+    assert 0.0 <= r["spread"] and "fixed rule" in r["sample"] and "two batches" in r["sample"]
+    if old is not None:
+        assert set(os.sched_getaffinity(0)) == old                      # the pinning is undone

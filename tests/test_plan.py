@@ -610,6 +610,27 @@ def test_k_pair_jobs_split_the_taps_of_the_long_classes_in_two(lib):
     lib.dgp2_free(h2); lib.dgp_free(h1)
 
 
+def test_which_classes_are_paired_depends_on_the_layer_plan_only(lib):
+    """The invariant behind "rows are independent of their batch" now that tiles ARE cut along K (gan_defense.rows_are_independent):
+    which tap classes are computed by K-pair jobs, and where their taps are split, is a function of the layer plan alone -- the
+    same for every row count, cutting threshold and slot count -- so an output element's summation tree never depends on the
+    call it is part of."""
+    for layer in (("deconv_bwd", 4, 4, 7, 7, 256, 128, 256), ("deconv_bwd", 4, 4, 8, 8, 256, 128, 256), ("deconv_bwd", 7, 7, 14, 14, 128, 64, 128),
+                  ("deconv_fwd", 4, 4, 7, 7, 256, 128, 128)):
+        h1, h2, info, b = batched(lib, *layer)
+        seen = {}
+        for n_rows, slots, slack in ((3, 512, 0.0), (70, 512, 0.0), (500, 768, 1e30), (500, 1280, 0.01), (2560, 512, 0.0), (2560, 768, 0.97)):
+            jobs = jobs_of(lib, h2, n_rows, slots, slack)
+            pr = (C.c_int * (4 * len(jobs)))(); lib.dgp2_job_pairs(h2, pr)
+            pr = np.array(pr).reshape(-1, 4)
+            for (cls, *_), (own, pid, role, _) in zip(jobs.tolist(), pr.tolist()):
+                key = (cls, role if pid else -1)
+                assert seen.setdefault(key, own) == own, (layer, n_rows, key)            # the same K extent per (class, half) everywhere
+            paired_now = {c for (c, r) in seen if r >= 0}
+            assert all((c, -1) not in seen for c in paired_now), (layer, n_rows)          # a class is paired in every list or in none
+        lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
 def test_jobs_balanced_builds_a_single_round_list_of_equal_work_per_cu(lib):
     """dg_plan.h jobs_balanced (TuneRecord.snake = 4): a list for ONE dispatch round -- at most cus * slots_per_cu jobs, CU b's jobs at
     the positions b, b + 256, ... -- whose tiles are cut (along M / N only) until the heaviest CU carries at most a few percent more
