@@ -7,24 +7,10 @@
 //   -> momentum update.
 // The L-th iteration runs the forward half only (the reference discards the L-th update), then the
 // per-image first-argmin over restarts gathers the output.  No host round trip inside the loop.
-#include <hip/hip_runtime.h>
+#include "dg_engine.h"
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <queue>
-#include <string>
-#include <vector>
-
-#include "../../include/defensegan_hip.h"
-#include "dg_kernels.h"
-#include "dg_plan.h"
-
-namespace {
+#pragma GCC visibility push(hidden)
+namespace dge {
 
 thread_local std::string g_err;
 
@@ -38,342 +24,10 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess)                                                                          \
-            return fail(DG_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-    } while (0)
-
-struct DeconvSpec {
-    const char* name;   // reference layer name
-    int cin, cout, h_in, e_used;
-    int act;            // 0 relu, 1 none, 2 final (sigmoid / tanh in the tail)
-    const char* bn;     // BN layer applied to this layer's output when use_bn ("" = none)
-};
-
-// One activation buffer: act[0] = Linear output [N, 16 positions, 4*net_dim]; act[d+1] = output of deconv d.
-struct ActInfo {
-    int pitch = 0;          // stored positions per spatial dimension
-    int valid = 0;          // leading positions that are consumed downstream (7 of 8 after the MNIST crop)
-    int C = 0;              // channels
-    int64_t row_floats = 0; // floats per latent row
-    bool has_bn = false;
-    std::string bn_name;
-    int bn_C = 0;           // BN columns (4096 features for BN1, channels otherwise)
-    int64_t bn_rows = 0;    // BN rows per latent row (1 for BN1, pitch^2 otherwise)
-    float* buf = nullptr;
-    float* xhat = nullptr;
-    float* scale = nullptr;   // [bn_C]
-    float* offset = nullptr;  // [bn_C]
-    float* fstats = nullptr;  // [2, bn_C]
-    float* bstats = nullptr;  // [2, bn_C]
-    float* block_sums = nullptr;  // [blocks][2][bn_C]: per-32-row-block column sums left by the producing GEMM's epilogue (EPI_BIAS_STATS)
-    int64_t block_cap = 0;        // blocks block_sums holds
-};
-
-// Job list of a position-batched launch (dg_gemm.hip), one per row count a layer has been run with.
-struct JobList {
-    int n_rows = 0, n_jobs = 0, min_level = 0;
-    int xcd_order = 0;             // 1 = head of the list re-arranged for XCD locality (dg_plan.h order_for_xcd)
-    int snake = 0;                 // 1 = every other round of #CUs jobs reversed (boustrophedon)
-    double slack = 0.0;            // the cutting threshold the list was built with (dg_plan.h build_jobs)
-    double taper = 0.0;            // JobModel::taper the list was built with
-    int prio = 0;                  // 1 = wave priorities by predicted job length (dg_plan.h assign_priorities)
-    int pair_kernel = 0;           // 1 = launched as the PAIR instantiation although it holds no pair (dg_plan.h TuneRecord::pair_kernel)
-    double xcd_head = 0.0;         // head fraction of the XCD-locality order
-    double predicted_us = 0.0;     // simulated makespan of the cost model
-    double measured_us = 0.0;      // duration measured when the list was chosen by timing (0 = chosen by the model)
-    dg::JobDesc* d_jobs = nullptr;
-    // K-pair jobs (dg_types.h): arrival counters and accumulator images, in the SAME allocation behind the job records
-    unsigned* d_pair_count = nullptr;
-    float* d_pair = nullptr;
-    size_t pair_count_stride = 0, pair_stride = 0;   // elements per copy: one copy per concurrent row group (option two_streams)
-    int pair_copies = 0;           // copies of the counters / images behind the job records (0 = the list has no pair)
-};
-
-// Job list of a fragment-order launch (dg_fgemm.hip): a pure function of (layer plan, row count), no timing
-struct FragList {
-    int n_rows = 0, n_jobs = 0;
-    dg::FragJob* d_jobs = nullptr;
-};
-
-struct GemmOp {
-    std::string name;
-    dg::BatchedPlan bplan;
-    std::vector<FragList> fjobs;
-    int family = 0;
-    dg::ClassDesc* d_cls = nullptr;
-    dg::TapEntry* d_btaps = nullptr;
-    int* d_pos_a = nullptr;
-    int* d_pos_out = nullptr;
-    std::vector<JobList> jobs;
-    int mode = 0;
-    const float* W = nullptr;
-    const float* bias = nullptr;
-    float* stats = nullptr;   // EPI_BIAS_STATS: the block sums of the activation this layer produces (ActInfo::block_sums)
-    int64_t stats_cap = 0;    // blocks that buffer holds
-};
-
-constexpr int kJobTraceCap = 65536;
-
-struct ProfEntry {
-    std::string name;
-    int64_t launches = 0;
-    double ms = 0.0;
-    double flops = 0.0;   // algorithmic FLOP of the measured launches
-};
-struct ProfPending {
-    int entry;
-    int e0, e1;          // indices into dg_handle::prof_events
-};
-
-}  // namespace
-
-struct dg_handle {
-    int arch = 0, latent = 0, net_dim = 0, use_bn = 0, device = 0;
-    int img_h = 0, img_c = 0, P = 0;
-    int lin_out = 0;
-    std::vector<DeconvSpec> dec;
-
-    // weights (device, engine-owned)
-    float* lin_w = nullptr;    // [latent][lin_out]   reference layout; K-contiguous operand of the backward
-    float* lin_wt = nullptr;   // [lin_out][latent]   K-contiguous operand of the forward
-    float* lin_b = nullptr;
-    float* lin_pack_fwd = nullptr; // lin_wt / lin_w in the MFMA fragment order of dg_linear.hip (dg_kernels.h lin_pack_index), or nullptr
-    float* lin_pack_bwd = nullptr;
-    std::vector<float> lin_w_host; // [latent][lin_out]: the packs are rebuilt when nsplit changes
-    std::vector<float*> F, Ft, bias;   // per deconv: [25][cout][cin], [25][cin][cout], [cout]
-    std::vector<float*> Fp;            // per non-final deconv: the forward filters in fragment order (dg_fgemm.hip), per tap slab
-                                       // [cout / 32][cin / 8][64][4]
-    // The fragment-order forward path (round 6; option frag_path, default on; conditions: frag_active()): F1 writes h1 in fragment
-    // order + gate bits, every forward deconv runs on dg_fgemm.hip (fragment-order input; output in fragment order, or NHWC for the
-    // layer the tail reads), the backward GEMMs take their ReluGrad gates from the bits and write the gradients into the NHWC buffers.
-    int frag_path = 0;
-    const unsigned* tune_gates = nullptr;   // set while prepare_rows times a backward layer's lists: the gate bits it will run with
-    std::vector<float*> actf;          // per activation d < nd - 1: fragment-order buffer (rows padded to 32)
-    std::vector<unsigned*> gate;       // per activation d < nd - 1: [rows][row_floats / 32] gate bits
-    float* tail_pack = nullptr;        // last deconv's filters in MFMA fragment order (forward tail GEMM)
-    float* tail_pack16 = nullptr;      // same, 16x16x4 fragments of the kh-aligned tiles (CelebA forward tail)
-    std::map<std::string, bool> have;
-
-    // ops
-    GemmOp F1, B1;
-    std::vector<GemmOp> Fd, Bd;   // per non-final deconv
-    // K slices of the Linear backward (one fixed value for every row count: the slice sums are added in slice order, so the
-    // result does not depend on the batch).  Measured 8 vs 16 (MI355X): 2560 rows 977.6 vs 975.5 img/s, 500 rows (the
-    // reference's default batch) 756.6 vs 777.9, CelebA 305.2 vs 305.2.
-    int nsplit = 16;
-    // The latent turn (Linear backward -> update -> Linear forward) on the weight-stationary kernels of dg_linear.hip when the
-    // shapes allow (any latent_dim that is a multiple of 32 up to 192 forward; latent_dim 128 and 256-wide K slices backward);
-    // 0 = the position-batched kernel as for every other layer.  Bit-identical either way (same fma chains, same K slices).
-    int latent_turn = 1;
-    int update_fold = 0;           // momentum update folded into the Linear backward launch (dg_linear.hip); needs latent_turn
-    unsigned* upd_count = nullptr; // one arrival counter per 32-row block (+ one per row group), zero between launches
-    int lin_groups_fwd = 0, lin_groups_bwd = 0;   // workgroups per column tile / K slice; 0 = pick from the CU count
-    int cu_count = 256;
-    double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan
-    // Resident workgroups per CU by (family, smallest level in the list) = what LDS admits: 160 KB / (64 | 80, 48, 32 KB of
-    // gemm_lds_bytes) = 2, 3, 5.  The kernel's __launch_bounds__(256, 2 / 3 / 4) is the MINIMUM occupancy the register allocator
-    // must leave room for, not a cap: the level-2 instantiations use 62-68 VGPRs, so registers admit 7 and LDS decides (5).
-    int job_slots_per_cu[2][3] = {{2, 3, 5}, {2, 3, 5}};
-    int job_min_level = -1;        // >= 0 forces the starting level of every list (measurement)
-    int job_tune = 1;              // 1 = time the candidate job lists on first use of a row count and keep the fastest
-    int job_taper_tune = 1;        // 1 = tapered lists (dg_plan.h JobModel::taper) are among the timed candidates
-    // Wave priorities by predicted job length (dg_types.h JobDesc::prio): 1 = the best lists of the timing are timed again with
-    // priorities and the faster form is kept, 0 = never (default), 2 = every list carries them (measurement, bit-identity tests)
-    int job_prio = 0;              // (measured, profiles/r05_ab_prio.txt: the arbiter follows the priorities, the launches last the same)
-    int job_spread = 0;            // 1 = the fastest multi-round lists are also timed in spread order (dg_plan.h spread_order); measured
-                                   // slower on every layer (profiles/r05_ab_list_orders.txt): off
-    // Batchnorm forward statistics from the producing GEMM's epilogue (per-32-row-block column sums, EPI_BIAS_STATS) instead of a
-    // pass over the pre-activations; 0 = the separate pass (cross-check)
-    int bn_fused = 1;
-    // The kernel has two instantiations per (family, epilogue, level): with and without the K-pair hand-off code.  A list without
-    // pairs needs neither, and hipcc allocates and schedules their main loops differently: measured on MNIST at 2560 rows the PAIR
-    // form is 0.7 % FASTER on Generator.3's backward and 0.6 % on Generator.2's forward, 0.3 % slower on Generator.3's forward
-    // (profiles/r05_ab_pair_kernel.txt).  1 = the two fastest lists without pairs are timed on both and the faster form is kept
-    // (default), 0 = never, 2 = always.
-    int job_pair_kernel = 1;
-    int job_balance = 1;           // 1 = lists that fit the resident slots are also offered in balance_order (dg_plan.h)
-    // > 0: lists are also offered to the timing in XCD-locality order (dg_plan.h order_for_xcd) with this head fraction.  Off:
-    // measured in round 3 (profiles/r03_exp_xcd_order.txt) -- the timing kept it for CelebA's Generator.5 backward only, the
-    // launch took the same time (465 vs 466 us), fetched the same bytes across the L2/fabric boundary (907 vs 910 MB raw) and
-    // clocked the same: one latent row of that layer's input is 256 KB, so the rows even a row-ordered resident set touches
-    // (~50 per XCD) are three times the 4 MB L2 -- the re-reads of the 25-tap pattern are served by the Infinity Cache either way.
-    double job_xcd_head = 0.0;
-    dg::JobModel job_model;
-    long long* d_job_trace = nullptr;
-    std::string job_trace_op;
-    int tail_dbg = 0;
-    int tail_prio = 0;       // wg_priority mode of the CelebA tail launches (dg_device.h): measured, no gain; off
-    int tail_bwd_bands = 1;
-    int tail_fwd16 = 1;
-    int tail_bwd_persist = 512;
-    int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
-                                   // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
-    int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)
-    int tail_pipe_version = 3;     // mnist_tail_pipe3_kernel / _pipe2_ / _pipe_kernel (dg_tail_mnist.hip)
-    long long* d_tail_trace = nullptr;   // [4096][8] phase cycle totals, allocated by option tail_trace
-    // 0: lr == rec_lr for every step -- what the reference executes (its decay's step variable is never advanced, gan.py:362-386).
-    // 1: the schedule the reference's code asks for, exponential_decay(rec_lr, k, ceil(0.8 L), 0.1, staircase) (base_model.py:186-192)
-    int lr_intended = 0;
-    // number of concurrent row groups (each on its own stream).  Off: measured again in round 3 on one box with 2 .. 8 groups,
-    // tuned and whole-tile job lists (profiles/r03_exp_stream_groups.txt): MNIST 2560 rows 966.7 vs 966.6 img/s with 2 groups,
-    // slower with 3+ (a queue only gets workgroup slots as the other's kernel retires them, so two MFMA-bound kernels do not
-    // overlap beyond their launch ends, and the half-size launches are less efficient); CelebA +0.9 %; 500 rows -13 %.
-    int two_streams = 0;
-    int two_stream_min_rows = 1024;
-    static constexpr int kMaxGroups = 8;
-    hipStream_t side_stream[kMaxGroups - 1] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};
-
-    // workspace
-    int64_t cap_rows = 0;
-    float *z = nullptr, *m = nullptr, *part = nullptr, *loss = nullptr, *y = nullptr;
-    float* xzero = nullptr;        // [P] zeros: stand-in target for dg_generate
-    std::vector<ActInfo> ai;       // per activation buffer (sizes, BN parameters)
-    std::vector<float*> act;       // act[0] = h1 [N, lin_out]; act[d+1] = output of deconv d (non-final)
-    std::vector<int64_t> act_row;  // floats per latent row
-    double* bn_part = nullptr;     // BN partial sums scratch
-    float* g6 = nullptr;           // CelebA: da6 [N, 64*64*3]
-    float* loss_part = nullptr;    // CelebA: [N, 8 bands, 4 waves] partial sums of squared error
-
-    // Replayed graphs of the L-step loop (option graph_max_rows): for call shapes of at most that many latent rows -- where a
-    // kernel lasts tens of microseconds and the ~1600 host enqueues of a call are a visible share -- dg_reconstruct captures the
-    // loop once per (B, R, L, lr, momentum, schedule) on an internal stream and replays it on the caller's.  Graph nodes hold
-    // fixed pointers: the loop reads the call's images from a staging copy (xbuf), and a graph dies with the job lists /
-    // workspace it points into (list_epoch).
-    struct LoopGraph { int B = 0, R = 0, L = 0; float lr = 0.f, momentum = 0.f; int lr_intended = 0; uint64_t epoch = 0; hipGraphExec_t exec = nullptr; };
-    std::vector<LoopGraph> graphs;
-    uint64_t list_epoch = 0;
-    // OFF by default (0).  Measured in round 4 on the reference's default batch (500 rows): 780.4 img/s replayed vs 779.5 enqueued
-    // (profiles/r04_exp_loop_graph.txt) -- the loop is not launch-bound (a kernel lasts 40 us on average) -- and on ROCm 7.2 a graph
-    // the CALLER captured of a call on this handle (tests/test_gpu_prepare.py) replays with wrong results once an internal replay
-    // has run between its capture and its replay (4 runs in 5; eager launches in between are harmless; tools/graph_interplay_repro.py).
-    int graph_max_rows = 0;
-    bool graph_broken = false;     // a capture / instantiate failed once: stay on the eager path
-    float* xbuf = nullptr;
-    int64_t xbuf_floats = 0;
-    hipStream_t cap_stream = nullptr;
-
-    // profiling
-    int prof_stride = 0;
-    std::vector<ProfEntry> prof;
-    std::vector<ProfPending> pending;
-    std::map<std::string, int> prof_index;
-    // Markers of the profiled launches, in stream order.  Consecutive launches SHARE the marker between them (the end of one
-    // is the start of the next), so the durations of a profiled step add up to its wall time exactly -- a separate event pair
-    // per launch counted every dispatch boundary twice (round 2: the breakdown summed 1.3 % above the timed step).
-    std::vector<hipEvent_t> prof_events;
-    hipStream_t prof_chain_stream = nullptr;
-    int prof_chain_last = -1;      // index of the marker recorded after the previous profiled launch, -1 = chain broken
-};
-
-namespace {
-
-int prof_slot(dg_handle* h, const std::string& name) {
-    auto it = h->prof_index.find(name);
-    if (it != h->prof_index.end()) return it->second;
-    h->prof.push_back(ProfEntry{name, 0, 0.0, 0.0});
-    h->prof_index[name] = (int)h->prof.size() - 1;
-    return (int)h->prof.size() - 1;
-}
-
-struct ProfScope {   // brackets one launch with stream markers when sampling is on for this iteration
-    dg_handle* h;
-    hipStream_t s;
-    bool on;
-    int entry = -1;
-    int i0 = -1;
-    double flops;
-    static int new_marker(dg_handle* h, hipStream_t s) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return -1;
-        if (hipEventRecord(e, s) != hipSuccess) { (void)hipEventDestroy(e); return -1; }
-        h->prof_events.push_back(e);
-        return (int)h->prof_events.size() - 1;
-    }
-    ProfScope(dg_handle* h_, hipStream_t s_, bool on_, const std::string& name, double flops_)
-        : h(h_), s(s_), on(on_), flops(flops_) {
-        if (!on) return;
-        entry = prof_slot(h, name);
-        // the marker after the previous profiled launch on this stream is this launch's start
-        i0 = (h->prof_chain_last >= 0 && h->prof_chain_stream == s) ? h->prof_chain_last : new_marker(h, s);
-        if (i0 < 0) on = false;
-    }
-    ~ProfScope() {
-        if (!on) return;
-        const int i1 = new_marker(h, s);
-        h->prof_chain_stream = s;
-        h->prof_chain_last = i1;
-        if (i1 < 0) return;
-        h->pending.push_back(ProfPending{entry, i0, i1});
-        h->prof[entry].flops += flops;
-    }
-};
-
-void prof_collect(dg_handle* h) {
-    for (auto& p : h->pending) {
-        float ms = 0.f;
-        if (hipEventSynchronize(h->prof_events[p.e1]) == hipSuccess &&
-            hipEventElapsedTime(&ms, h->prof_events[p.e0], h->prof_events[p.e1]) == hipSuccess) {
-            h->prof[p.entry].ms += ms;
-            h->prof[p.entry].launches += 1;
-        }
-    }
-    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-    h->prof_events.clear();
-    h->pending.clear();
-    h->prof_chain_last = -1;
-}
-
 // A failed launch (bad configuration, LDS limit, ...) is reported by the layer it happened in, not at the end of the call.
 int launch_check(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
-    return DG_OK;
-}
-
-// forget every tuned job list (an option that changes how the lists are built or timed was set)
-void drop_job_lists(dg_handle* h) {
-    ++h->list_epoch;
-    for (GemmOp* op : {&h->F1, &h->B1}) { for (auto& jl : op->jobs) (void)hipFree(jl.d_jobs); op->jobs.clear(); }
-    for (auto* vec : {&h->Fd, &h->Bd})
-        for (auto& op : *vec) { for (auto& jl : op.jobs) (void)hipFree(jl.d_jobs); op.jobs.clear(); }
-}
-
-void free_batched(GemmOp& op) {
-    for (auto& jl : op.jobs)
-        if (jl.d_jobs) (void)hipFree(jl.d_jobs);
-    op.jobs.clear();
-    for (auto& fl : op.fjobs)
-        if (fl.d_jobs) (void)hipFree(fl.d_jobs);
-    op.fjobs.clear();
-    if (op.d_cls) { (void)hipFree(op.d_cls); op.d_cls = nullptr; }
-    if (op.d_btaps) { (void)hipFree(op.d_btaps); op.d_btaps = nullptr; }
-    if (op.d_pos_a) { (void)hipFree(op.d_pos_a); op.d_pos_a = nullptr; }
-    if (op.d_pos_out) { (void)hipFree(op.d_pos_out); op.d_pos_out = nullptr; }
-}
-
-// `base` = the layer planned with one PosEntry per position (bn == ncols)
-int upload_batched(GemmOp& op, const dg::LayerPlan& base) {
-    free_batched(op);
-    // the job shapes are 64 / 128 columns wide and the kernel never masks columns or K: anything else would read and write
-    // out of bounds (dg_create's latent_dim % 64 / net_dim % 64 checks guarantee this for the two generators)
-    if (base.ncols % 64 != 0 || base.kch % 32 != 0 || base.kch <= 0)
-        return fail(DG_E_INVALID, "layer %s: %d output columns / K %d per tap (need multiples of 64 / 32)", op.name.c_str(), base.ncols, base.kch);
-    op.bplan = dg::make_batched(base);
-    op.family = (base.ncols % 128 == 0) ? 0 : 1;
-    const dg::BatchedPlan& b = op.bplan;
-    auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(dst, bytes ? bytes : 16);
-        if (e == hipSuccess && bytes) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    HIP_TRY(up((void**)&op.d_cls, b.cls.data(), b.cls.size() * sizeof(dg::ClassDesc)));
-    HIP_TRY(up((void**)&op.d_btaps, b.taps.data(), b.taps.size() * sizeof(dg::TapEntry)));
-    HIP_TRY(up((void**)&op.d_pos_a, b.pos_a.data(), b.pos_a.size() * sizeof(int)));
-    HIP_TRY(up((void**)&op.d_pos_out, b.pos_out.data(), b.pos_out.size() * sizeof(int)));
     return DG_OK;
 }
 
@@ -524,382 +178,6 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     return DG_OK;
 }
 
-dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const float* A, float* Out, int group = 0) {
-    dg::GemmArgs a;
-    a.A = A;
-    a.W = op.W;
-    a.Out = Out;
-    a.bias = op.bias;
-    a.jobs = jl.d_jobs;
-    a.pair_scratch = jl.d_pair ? jl.d_pair + (size_t)group * jl.pair_stride : nullptr;
-    a.pair_count = jl.d_pair_count ? jl.d_pair_count + (size_t)group * jl.pair_count_stride : nullptr;
-    // a list without pairs that was timed faster on the PAIR instantiation (same arithmetic, another register allocation): any
-    // non-null pointer selects it, nothing reads it
-    if (jl.pair_kernel && !a.pair_scratch) a.pair_scratch = reinterpret_cast<float*>(jl.d_jobs);
-    a.cls = op.d_cls;
-    a.taps = op.d_btaps;
-    a.pos_a = op.d_pos_a;
-    a.pos_out = op.d_pos_out;
-    a.a_rowstride = op.bplan.a_rowstride;
-    a.out_rowstride = op.bplan.out_rowstride;
-    a.w_rowstride = op.bplan.w_rowstride;
-    a.kch = op.bplan.kch;
-    a.mode = op.mode;
-    a.stats = op.stats;
-    a.stats_cols = op.bplan.ncols;
-    a.gate_bits = nullptr;
-    a.gate_words = 0;
-    a.n_jobs = jl.n_jobs;
-    a.min_level = jl.min_level;
-#ifdef DG_MEASURE
-    // the trace buffer holds kJobTraceCap records (one per workgroup): larger launches are not traced
-    a.trace = (h->d_job_trace && op.name == h->job_trace_op && jl.n_jobs <= kJobTraceCap) ? h->d_job_trace : nullptr;
-#endif
-    return a;
-}
-
-// copies of a list's K-pair scratch: one per row group that may run concurrently (option two_streams)
-int pair_copies(const dg_handle* h) { return h->two_streams > 1 ? std::min(h->two_streams, (int)dg_handle::kMaxGroups) : 1; }
-
-bool upload_jobs(JobList& jl, const std::vector<dg::JobDesc>& jobs, int family, int copies) {
-    jl.n_jobs = (int)jobs.size();
-    // one allocation: [job records][pair counters x copies][pair accumulator images x copies] (every free of d_jobs frees all of
-    // it).  A copy per row group that may launch this list concurrently on its own stream (two groups of equal size share a list)
-    const dg::PairNeeds pn = dg::pair_needs(jobs, family);
-    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t jobs_bytes = up((jobs.size() + 1) * sizeof(dg::JobDesc));
-    const size_t count_bytes = up((size_t)pn.pairs * sizeof(unsigned));
-    const size_t img_bytes = up((size_t)pn.floats * sizeof(float));
-    if (!pn.pairs) copies = 0;
-    char* base = nullptr;
-    if (hipMalloc(&base, jobs_bytes + (count_bytes + img_bytes) * (size_t)copies) != hipSuccess) return false;
-    jl.d_jobs = reinterpret_cast<dg::JobDesc*>(base);
-    jl.d_pair_count = pn.pairs ? reinterpret_cast<unsigned*>(base + jobs_bytes) : nullptr;
-    jl.d_pair = pn.pairs ? reinterpret_cast<float*>(base + jobs_bytes + count_bytes * (size_t)copies) : nullptr;
-    jl.pair_count_stride = count_bytes / sizeof(unsigned);
-    jl.pair_stride = img_bytes / sizeof(float);
-    jl.pair_copies = copies;
-    if (hipMemcpy(jl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::JobDesc), hipMemcpyHostToDevice) != hipSuccess ||
-        (pn.pairs && hipMemset(jl.d_pair_count, 0, count_bytes * (size_t)copies) != hipSuccess)) {
-        (void)hipFree(jl.d_jobs);
-        jl.d_jobs = nullptr; jl.d_pair_count = nullptr; jl.d_pair = nullptr;
-        return false;
-    }
-    return true;
-}
-
-// The arrival counters of a list's K-pair jobs return to zero by themselves (the second arrival wraps them), but a launch that died
-// between the two arrivals of a pair -- a device fault, a killed process that shared the handle's memory -- would leave a counter
-// at 1, and the FIRST arriver of the next call would then add a stale image and run the epilogue: silently wrong numbers.  Every
-// call therefore clears the counters of the lists it is about to launch, on its own stream (a few hundred bytes per list: free,
-// and capturable).  Same treatment as the folded update's counters.
-int clear_pair_counters(dg_handle* h, int n_rows, hipStream_t s) {
-    for (auto* vec : {&h->Fd, &h->Bd})
-        for (auto& op : *vec)
-            for (auto& jl : op.jobs)
-                if (jl.n_rows == n_rows && jl.d_pair_count && jl.pair_copies > 0)
-                    HIP_TRY(hipMemsetAsync(jl.d_pair_count, 0, jl.pair_count_stride * sizeof(unsigned) * (size_t)jl.pair_copies, s));
-    for (GemmOp* op : {&h->F1, &h->B1})
-        for (auto& jl : op->jobs)
-            if (jl.n_rows == n_rows && jl.d_pair_count && jl.pair_copies > 0)
-                HIP_TRY(hipMemsetAsync(jl.d_pair_count, 0, jl.pair_count_stride * sizeof(unsigned) * (size_t)jl.pair_copies, s));
-    return DG_OK;
-}
-
-// Job list of `op` for this row count (built on first use, kept on the device).
-//
-// Candidates: a list that starts with full tiles leaves room for 2 (family 0) / 3 (family 1) workgroups per CU; lists cut
-// to halves or quarters from the start need less LDS and registers (dg_gemm.hip, MINLEVEL) and get more slots; each with a
-// few cutting thresholds (dg_plan.h build_jobs).  Every candidate computes bit-identical results (cuts are along M / N
-// only), so the choice is purely one of speed: with `job_tune` the candidates are TIMED on the layer's real operands (the
-// launch is repeated on the actual input; an in-place ReluGrad layer writes to a scratch copy of its output) and the fastest
-// is kept; without it the cost model's simulated makespan decides.
-const JobList* find_jobs(const GemmOp& op, int n_rows) {
-    for (const auto& jl : op.jobs)
-        if (jl.n_rows == n_rows) return &jl;
-    return nullptr;
-}
-
-const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, float* Out, hipStream_t s) {
-    if (const JobList* have = find_jobs(op, n_rows)) return have;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-    struct Cand { JobList jl; std::vector<dg::JobDesc> jobs; float ms = 0.f; };
-    std::vector<Cand> cands;
-    const int n_levels = 3;
-    const bool tune = h->job_tune && h->job_slack <= 0.0 && A && Out;
-    // (slack, taper) pairs offered to the timing: the cutting thresholds as before, plus tapered lists (dg_plan.h JobModel::taper)
-    const double slacks_tune[] = {1e30, 0.85, 0.92, 0.97, 1.0, 1.04, 1.1, 1e30, 1e30, 1e30, 1.0, 1.0, 1.0};
-    const double tapers_tune[] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.5, 0.65, 0.8, 0.5, 0.65, 0.8};
-    const double slack_one[] = {h->job_slack};
-    const double taper_one[] = {h->job_model.taper};
-    const double* slacks = tune ? slacks_tune : slack_one;
-    const double* tapers = tune ? tapers_tune : taper_one;
-    const int n_slacks = tune ? (h->job_taper_tune ? 13 : 7) : 1;
-    for (int lvl = 0; lvl < n_levels; ++lvl) {
-        if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
-        for (int k = 0; k < n_slacks; ++k) {
-            Cand c;
-            c.jl.n_rows = n_rows;
-            c.jl.min_level = lvl;
-            c.jl.slack = slacks[k];
-            c.jl.taper = tapers[k];
-            dg::JobModel jm = h->job_model;
-            jm.taper = tapers[k];
-            c.jobs = dg::build_jobs(op.bplan, n_rows, op.family, cus * h->job_slots_per_cu[op.family][lvl], slacks[k],
-                                    jm, &c.jl.predicted_us, lvl);
-            if (h->job_pair_kernel >= 2) c.jl.pair_kernel = 1;
-            if (h->job_prio >= 2) {
-                c.jl.prio = 1;
-                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], jm, 1);
-            }
-            auto add = [&](Cand&& x) {
-                for (const Cand& o : cands)
-                    if (o.jl.min_level == x.jl.min_level && o.jobs.size() == x.jobs.size() &&
-                        std::memcmp(o.jobs.data(), x.jobs.data(), x.jobs.size() * sizeof(dg::JobDesc)) == 0) return;
-                cands.push_back(std::move(x));
-            };
-            // A list that fits the resident slots is dispatched in one go, workgroup i to CU ~ i mod #CUs: with the jobs in
-            // descending order CU 0 collects the longest of every round and the last CU the shortest.  Second candidate:
-            // every other round of #CUs jobs reversed (boustrophedon), which evens the per-CU sums out (small batches).
-            const size_t slots = (size_t)cus * h->job_slots_per_cu[op.family][lvl];
-            // Lists of several dispatch rounds: second candidate in XCD-locality order (a permutation; kept only if it is timed
-            // faster -- without timing the cost model cannot see the difference, so it is not offered)
-            if (tune && h->job_xcd_head > 0.0 && c.jobs.size() > (size_t)cus) {
-                Cand lx;
-                lx.jl = c.jl;
-                lx.jl.xcd_order = 1;
-                lx.jl.xcd_head = h->job_xcd_head;
-                lx.jobs = c.jobs;
-                dg::order_for_xcd(lx.jobs, n_rows, h->job_xcd_head);
-                lx.jl.predicted_us = dg::simulate_jobs(op.bplan, lx.jobs, op.family, (int)slots, h->job_model);
-                // row-major order gives up longest-first: with only 2-3 dispatch rounds (MNIST at 2560 rows) the long jobs of
-                // the last rows then end the launch 10-60 % late in the simulation -- such lists are not worth timing; with ten
-                // rounds (CelebA's 32x32 layers) the order costs nothing
-                if (lx.jl.predicted_us <= 1.03 * c.jl.predicted_us) add(std::move(lx));
-            }
-            if (tune && c.jobs.size() <= slots && c.jobs.size() > (size_t)cus) {
-                Cand sn;
-                sn.jl = c.jl;
-                sn.jl.snake = 1;
-                sn.jobs = c.jobs;
-                dg::snake_order(sn.jobs, cus);
-                // third candidate: the jobs partitioned into per-CU sets of equal predicted work (dg_plan.h balance_order)
-                Cand bl;
-                bl.jl = c.jl;
-                bl.jl.snake = 2;
-                bl.jobs = c.jobs;
-                dg::balance_order(op.bplan, bl.jobs, op.family, cus, h->job_slots_per_cu[op.family][lvl], jm);
-                add(std::move(c));
-                add(std::move(sn));
-                if (h->job_balance) add(std::move(bl));
-            } else {
-                add(std::move(c));
-            }
-        }
-    }
-    // lists BUILT for one dispatch round with the work balanced over the CUs (dg_plan.h jobs_balanced), one per starting level
-    if (tune && h->job_balance >= 1) {
-        for (int lvl = 0; lvl < n_levels; ++lvl) {
-            if (h->job_min_level >= 0 && lvl != std::min(h->job_min_level, n_levels - 1)) continue;
-            Cand c;
-            c.jl.n_rows = n_rows;
-            c.jl.min_level = lvl;
-            c.jl.snake = 4;
-            c.jobs = dg::jobs_balanced(op.bplan, n_rows, op.family, cus, h->job_slots_per_cu[op.family][lvl], lvl, h->job_model);
-            if (c.jobs.empty()) continue;
-            c.jl.predicted_us = dg::simulate_jobs(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], h->job_model);
-            if (h->job_pair_kernel >= 2) c.jl.pair_kernel = 1;
-            if (h->job_prio >= 2) {
-                c.jl.prio = 1;
-                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][lvl], h->job_model, 1);
-            }
-            cands.push_back(std::move(c));
-        }
-    }
-    if (cands.empty()) return nullptr;
-    size_t best = 0;
-    for (size_t i = 1; i < cands.size(); ++i)
-        if (cands[i].jl.predicted_us < cands[best].jl.predicted_us) best = i;
-    // launches of several milliseconds have thousands of jobs per slot wave: the lists differ by < 1 % there, not worth timing
-    if (tune && cands.size() > 1 && cands[best].jl.predicted_us < 3000.0) {
-        float* scratch = nullptr;
-        float* out = Out;
-        const size_t out_bytes = (size_t)n_rows * op.bplan.out_rowstride * sizeof(float);
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
-        if (ok && op.mode == dg::EPI_MASK) {          // in place over its gates: time it on a copy
-            ok = hipMalloc(&scratch, out_bytes) == hipSuccess &&
-                 hipMemcpyAsync(scratch, Out, out_bytes, hipMemcpyDeviceToDevice, s) == hipSuccess;
-            out = scratch;
-        }
-        // One untimed launch keeps the stream busy while the timed ones are queued behind it, so the interval between the
-        // two events holds no host submission gaps; short layers are repeated more often.
-        auto time_list = [&](const JobList& jl, int scale, float* ms_out) {
-            dg::GemmArgs a = gemm_args(h, op, jl, A, out);
-            if (h->tune_gates && op.mode == dg::EPI_MASK) {          // the launch this layer will really make (fragment-order path)
-                a.mode = dg::EPI_MASK_BITS;
-                a.gate_bits = h->tune_gates;
-                a.gate_words = (int)(op.bplan.out_rowstride / 32);
-            }
-#ifdef DG_MEASURE
-            a.trace = nullptr;                       // candidate launches are not the traced ones
-#endif
-            const int reps = scale * std::max(2, std::min(16, (int)(1500.0 / std::max(jl.predicted_us, 1.0))));
-            dg::launch_gemm(op.family, a, s);
-            (void)hipEventRecord(e0, s);
-            for (int rep = 0; rep < reps; ++rep) dg::launch_gemm(op.family, a, s);
-            (void)hipEventRecord(e1, s);
-            float ms = 0.f;
-            if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return false;
-            *ms_out = ms / reps;
-            return true;
-        };
-        // Two stages (the tapered lists doubled the candidates, and every first use of a call shape -- the ragged last batch of
-        // an evaluation included -- pays for them): the plain lists of every starting level first; tapered lists are then timed
-        // only for the levels whose best plain list came within 2 % of the best overall (a taper re-cuts the END of a list, it
-        // does not make up for a starting level that is 5-10 % behind).
-        float level_best[3] = {1e30f, 1e30f, 1e30f};
-        for (size_t i = 0; ok && i < cands.size(); ++i) {
-            Cand& c = cands[i];
-            if (c.jl.taper > 0.0) continue;
-            ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
-            if (ok && c.ms < level_best[c.jl.min_level]) level_best[c.jl.min_level] = c.ms;
-        }
-        const float plain_best = std::min(level_best[0], std::min(level_best[1], level_best[2]));
-        for (size_t i = 0; ok && i < cands.size(); ++i) {
-            Cand& c = cands[i];
-            if (c.jl.taper <= 0.0) continue;
-            if (level_best[c.jl.min_level] > 1.02f * plain_best) { c.ms = 1e30f; continue; }      // never uploaded, never kept
-            ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
-        }
-        if (ok && h->job_spread) {
-            // the three fastest multi-round lists so far, once more in spread order (dg_plan.h spread_order: same jobs, desynchronised)
-            std::vector<size_t> top;
-            for (size_t i = 0; i < cands.size(); ++i)
-                if (cands[i].ms < 1e29f && cands[i].jl.snake == 0 && !cands[i].jl.xcd_order &&
-                    cands[i].jobs.size() > (size_t)cus * h->job_slots_per_cu[op.family][cands[i].jl.min_level]) top.push_back(i);
-            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
-            if (top.size() > 3) top.resize(3);
-            for (size_t k = 0; ok && k < top.size(); ++k) {
-                Cand c;
-                c.jl = cands[top[k]].jl;
-                c.jl.d_jobs = nullptr;
-                c.jl.snake = 3;
-                c.jobs = cands[top[k]].jobs;
-                dg::JobModel jm = h->job_model;
-                jm.taper = c.jl.taper;
-                dg::spread_order(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][c.jl.min_level], jm);
-                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
-                cands.push_back(std::move(c));
-            }
-        }
-        if (ok && h->job_pair_kernel >= 1) {
-            // the two fastest lists without K-pair jobs, once more on the PAIR instantiation of the kernel
-            std::vector<size_t> top;
-            for (size_t i = 0; i < cands.size(); ++i)
-                if (cands[i].ms < 1e29f && cands[i].jl.d_jobs && !cands[i].jl.d_pair) top.push_back(i);
-            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
-            if (top.size() > 2) top.resize(2);
-            for (size_t k = 0; ok && k < top.size(); ++k) {
-                Cand c;
-                c.jl = cands[top[k]].jl;
-                c.jl.d_jobs = nullptr;
-                c.jl.pair_kernel = 1;
-                c.jobs = cands[top[k]].jobs;
-                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
-                cands.push_back(std::move(c));
-            }
-        }
-        if (ok && h->job_prio == 1) {
-            // the three fastest lists so far, once more with wave priorities by predicted job length (same jobs, same order)
-            std::vector<size_t> top;
-            for (size_t i = 0; i < cands.size(); ++i) if (cands[i].ms < 1e29f) top.push_back(i);
-            std::sort(top.begin(), top.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
-            if (top.size() > 3) top.resize(3);
-            for (size_t k = 0; ok && k < top.size(); ++k) {
-                Cand c;
-                c.jl = cands[top[k]].jl;
-                c.jl.d_jobs = nullptr;
-                c.jl.prio = 1;
-                c.jobs = cands[top[k]].jobs;
-                dg::JobModel jm = h->job_model;
-                jm.taper = c.jl.taper;
-                dg::assign_priorities(op.bplan, c.jobs, op.family, cus * h->job_slots_per_cu[op.family][c.jl.min_level], jm, 1);
-                bool any = false;
-                for (const dg::JobDesc& j : c.jobs) any = any || j.prio != 0;
-                if (!any) continue;
-                ok = upload_jobs(c.jl, c.jobs, op.family, pair_copies(h)) && time_list(c.jl, 1, &c.ms);
-                cands.push_back(std::move(c));
-            }
-        }
-        if (ok) {
-            for (size_t i = 0; i < cands.size(); ++i)
-                if (cands[i].ms < cands[best].ms) best = i;
-            // The first pass is a few launches per candidate while the clocks may still be settling: candidates within 3 % of
-            // its winner (at most 4) are timed again, longer, once in order and once in reverse; the sum decides.
-            std::vector<size_t> fin;
-            for (size_t i = 0; i < cands.size(); ++i)
-                if (cands[i].ms <= 1.03f * cands[best].ms) fin.push_back(i);
-            std::sort(fin.begin(), fin.end(), [&](size_t x, size_t y) { return cands[x].ms < cands[y].ms; });
-            if (fin.size() > 4) fin.resize(4);
-            if (fin.size() > 1) {
-                std::vector<float> sum(fin.size(), 0.f);
-                bool ok2 = true;
-                for (int pass = 0; ok2 && pass < 2; ++pass)
-                    for (size_t k = 0; ok2 && k < fin.size(); ++k) {
-                        const size_t q = pass == 0 ? k : fin.size() - 1 - k;
-                        float ms = 0.f;
-                        ok2 = time_list(cands[fin[q]].jl, 2, &ms);
-                        sum[q] += ms;
-                    }
-                if (ok2) {
-                    size_t w = 0, pref = 0;
-                    for (size_t k = 0; k < fin.size(); ++k) {
-                        cands[fin[k]].ms = 0.5f * sum[k];
-                        if (sum[k] < sum[w]) w = k;
-                        if (cands[fin[k]].jl.predicted_us < cands[fin[pref]].jl.predicted_us) pref = k;
-                    }
-                    // finalists within 0.7 % of each other are a coin toss from run to run (seen: Generator.2's backward taking a
-                    // level-0 list in one process and a level-1 list in the next): then the cost model's favourite among them is
-                    // kept, so that two runs on the same device make the same choice unless one list is measurably faster
-                    // (not between the two kernel forms of ONE list: there the timing compares like with like, and either choice
-                    // gives the same results)
-                    auto same_list = [&](const JobList& a, const JobList& b) {
-                        return a.min_level == b.min_level && a.slack == b.slack && a.taper == b.taper && a.snake == b.snake &&
-                               a.xcd_order == b.xcd_order && a.prio == b.prio && a.n_jobs == b.n_jobs;
-                    };
-                    if (sum[pref] <= 1.007f * sum[w] && !same_list(cands[fin[pref]].jl, cands[fin[w]].jl)) w = pref;
-                    best = fin[w];
-                }
-            }
-            cands[best].jl.measured_us = cands[best].ms * 1e3;
-            if (getenv("DG_TUNE_VERBOSE")) {
-                for (size_t i = 0; i < cands.size(); ++i)
-                    if (cands[i].ms < 1e29f)
-                    fprintf(stderr, "[dg tune] %s rows %d level %d%s%s%s slack %-6.3g taper %-4.2f jobs %5d model %8.1f us measured %8.1f us%s\n", op.name.c_str(),
-                            n_rows, cands[i].jl.min_level, cands[i].jl.xcd_order ? " xcd" : "    ", cands[i].jl.snake == 4 ? " built" : cands[i].jl.snake == 3 ? " sprd " : cands[i].jl.snake == 2 ? " balan" : cands[i].jl.snake ? " snake" : "      ", cands[i].jl.pair_kernel ? " pk  " : cands[i].jl.prio ? " prio" : "     ",
-                            cands[i].jl.slack, cands[i].jl.taper, (int)cands[i].jobs.size(), cands[i].jl.predicted_us, cands[i].ms * 1e3,
-                            i == best ? "  <- kept" : "");
-            }
-        }
-        for (size_t i = 0; i < cands.size(); ++i)
-            if (i != best && cands[i].jl.d_jobs) { (void)hipFree(cands[i].jl.d_jobs); cands[i].jl.d_jobs = nullptr; }
-        if (scratch) (void)hipFree(scratch);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-    }
-    JobList jl = cands[best].jl;
-    if (!jl.d_jobs && !upload_jobs(jl, cands[best].jobs, op.family, pair_copies(h))) return nullptr;
-    if (op.jobs.size() >= 16) {                 // callers with many distinct batch sizes: keep the table bounded
-        (void)hipFree(op.jobs.front().d_jobs);
-        op.jobs.erase(op.jobs.begin());
-    }
-    op.jobs.push_back(jl);
-    ++h->list_epoch;
-    return &op.jobs.back();
-}
-
 // F1 / B1 on the weight-stationary kernels (dg_linear.hip)?
 bool lin_stationary(const dg_handle* h, const GemmOp& op) {
     if (!h->latent_turn) return false;
@@ -926,29 +204,6 @@ bool frag_shapes_ok(const dg_handle* h) {
     return h->lin_out % 128 == 0;
 }
 bool frag_on(const dg_handle* h) { return frag_active(h) && frag_shapes_ok(h) && h->actf.size() == h->dec.size() && h->actf[0] != nullptr; }
-
-const FragList* find_frag_jobs(const GemmOp& op, int n_rows) {
-    for (const auto& fl : op.fjobs)
-        if (fl.n_rows == n_rows) return &fl;
-    return nullptr;
-}
-
-const FragList* get_frag_jobs(GemmOp& op, int n_rows) {
-    if (const FragList* have = find_frag_jobs(op, n_rows)) return have;
-    const std::vector<dg::FragJob> jobs = dg::build_frag_jobs(op.bplan, n_rows);
-    if (jobs.empty()) return nullptr;
-    FragList fl;
-    fl.n_rows = n_rows;
-    fl.n_jobs = (int)jobs.size();
-    if (hipMalloc(&fl.d_jobs, jobs.size() * sizeof(dg::FragJob)) != hipSuccess) return nullptr;
-    if (hipMemcpy(fl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::FragJob), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(fl.d_jobs);
-        return nullptr;
-    }
-    if (op.fjobs.size() >= 16) { (void)hipFree(op.fjobs.front().d_jobs); op.fjobs.erase(op.fjobs.begin()); }
-    op.fjobs.push_back(fl);
-    return &op.fjobs.back();
-}
 
 // One forward deconv on dg_fgemm.hip: A in fragment order; Out in fragment order (+ gate bits) or NHWC (the layer the tail reads)
 int run_frag(dg_handle* h, GemmOp& op, int d, const float* A, float* Out, bool out_frag, unsigned* gates, int n_rows, hipStream_t s, bool prof) {
@@ -1452,7 +707,8 @@ int check_ready(dg_handle* h) {
     return DG_OK;
 }
 
-}  // namespace
+}  // namespace dge
+#pragma GCC visibility pop
 
 extern "C" {
 
@@ -1876,342 +1132,6 @@ int dg_loss_grad(dg_handle* h, const float* x, const float* z, int B, int R, flo
     }
     HIP_TRY(hipGetLastError());
     return DG_OK;
-}
-
-// ---- tuning export / import ---------------------------------------------------------------------------------------------
-// The job list a layer runs with for a row count is chosen by TIMING candidates (get_jobs), so two processes -- the bench and a
-// profiler pass, or the ranks of a multi-GPU run -- can settle on different lists for the same layer.  Every list is a pure
-// function of (layer plan, row count, starting level, cutting threshold, order variant): exporting those few numbers and
-// importing them elsewhere reproduces the lists exactly, without timing.
-int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
-    if (!h) return fail(DG_E_INVALID, "null handle");
-    std::string out;
-    char line[256];
-    snprintf(line, sizeof line, "dgtune 1 arch %d latent %d net_dim %d use_bn %d nsplit %d cus %d\n", h->arch, h->latent, h->net_dim,
-             h->use_bn, h->nsplit, h->cu_count);
-    out += line;
-    auto dump = [&](const GemmOp& op) {
-        for (const JobList& jl : op.jobs) {
-            dg::TuneRecord r;
-            r.op = op.name; r.n_rows = jl.n_rows; r.min_level = jl.min_level; r.slack = jl.slack; r.snake = jl.snake;
-            r.xcd_order = jl.xcd_order; r.xcd_head = jl.xcd_head; r.n_jobs = jl.n_jobs; r.measured_us = jl.measured_us; r.taper = jl.taper;
-            r.prio = jl.prio; r.pair_kernel = jl.pair_kernel;
-            out += dg::format_tune_record(r);
-        }
-    };
-    dump(h->F1);
-    for (const auto& op : h->Fd) dump(op);
-    for (const auto& op : h->Bd) dump(op);
-    dump(h->B1);
-    const int64_t need = (int64_t)out.size() + 1;
-    if (buf && cap >= need) std::memcpy(buf, out.c_str(), (size_t)need);
-    else if (buf && cap > 0) buf[0] = 0;
-    return need;
-}
-
-int dg_import_tuning(dg_handle* h, const char* text) {
-    if (!h || !text) return fail(DG_E_INVALID, "null argument");
-    HIP_TRY(hipSetDevice(h->device));
-    const char* p = text;
-    int ver = 0, arch = 0, latent = 0, net_dim = 0, use_bn = 0, nsplit = 0, cus = 0, used = 0;
-    if (sscanf(p, "dgtune %d arch %d latent %d net_dim %d use_bn %d nsplit %d cus %d%n", &ver, &arch, &latent, &net_dim, &use_bn, &nsplit, &cus, &used) != 7 || ver != 1)
-        return fail(DG_E_INVALID, "not a dg_export_tuning text (header)");
-    if (arch != h->arch || latent != h->latent || net_dim != h->net_dim || use_bn != h->use_bn || nsplit != h->nsplit || cus != h->cu_count)
-        return fail(DG_E_INVALID, "tuning was exported for another configuration (arch %d latent %d net_dim %d use_bn %d nsplit %d, %d CUs)",
-                    arch, latent, net_dim, use_bn, nsplit, cus);
-    p += used;
-    std::vector<GemmOp*> ops = {&h->F1, &h->B1};
-    for (auto& op : h->Fd) ops.push_back(&op);
-    for (auto& op : h->Bd) ops.push_back(&op);
-    HIP_TRY(hipDeviceSynchronize());      // lists that are replaced may still be in use by queued launches
-    int n_imported = 0;
-    for (;;) {
-        dg::TuneRecord r;
-        if (!dg::parse_tune_record(&p, &r)) {
-            if (*p) return fail(DG_E_INVALID, "malformed tuning record near '%.40s'", p);
-            break;
-        }
-        GemmOp* op = nullptr;
-        for (GemmOp* o : ops) if (o->name == r.op) op = o;
-        if (!op || r.n_rows < 1 || r.n_rows > (1 << 24) || r.min_level < 0 || r.min_level > 2 || r.prio < 0 || r.prio > 1 || r.pair_kernel < 0 || r.pair_kernel > 1)
-            return fail(DG_E_INVALID, "tuning record for unknown layer '%s' / bad row count %d / level %d", r.op.c_str(), r.n_rows, r.min_level);
-        JobList jl;
-        jl.n_rows = r.n_rows; jl.min_level = r.min_level; jl.slack = r.slack; jl.snake = r.snake; jl.xcd_order = r.xcd_order;
-        jl.xcd_head = r.xcd_head; jl.measured_us = r.measured_us; jl.taper = r.taper; jl.prio = r.prio; jl.pair_kernel = r.pair_kernel;
-        const std::vector<dg::JobDesc> jobs = dg::jobs_from_record(op->bplan, op->family, h->cu_count, h->job_slots_per_cu[op->family][r.min_level],
-                                                                   r, h->job_model, &jl.predicted_us);
-        if ((int)jobs.size() != r.n_jobs)
-            return fail(DG_E_INVALID, "layer %s, %d rows: the record describes %d jobs, this build makes %d (other cost model or planner)",
-                        r.op.c_str(), r.n_rows, r.n_jobs, (int)jobs.size());
-        if (!upload_jobs(jl, jobs, op->family, pair_copies(h))) return fail(DG_E_NOMEM, "cannot upload the job list of layer %s", r.op.c_str());
-        ++h->list_epoch;                 // from here on lists are replaced: a captured loop may point at one (also when a later record fails)
-        for (auto it = op->jobs.begin(); it != op->jobs.end();)
-            if (it->n_rows == r.n_rows) { (void)hipFree(it->d_jobs); it = op->jobs.erase(it); } else ++it;
-        if (op->jobs.size() >= 16) { (void)hipFree(op->jobs.front().d_jobs); op->jobs.erase(op->jobs.begin()); }
-        op->jobs.push_back(jl);
-        ++n_imported;
-    }
-    return n_imported;
-}
-
-int dg_profile_enable(dg_handle* h, int on) {
-    if (!h) return fail(DG_E_INVALID, "null handle");
-    h->prof_stride = on > 0 ? on : 0;
-    return DG_OK;
-}
-int dg_profile_count(dg_handle* h) {
-    if (!h) return fail(DG_E_INVALID, "null handle");
-    prof_collect(h);
-    return (int)h->prof.size();
-}
-int dg_profile_read(dg_handle* h, int i, char* name, int name_len, int64_t* launches, double* total_ms, double* flops) {
-    if (!h) return fail(DG_E_INVALID, "null handle");
-    prof_collect(h);
-    if (i < 0 || i >= (int)h->prof.size()) return fail(DG_E_INVALID, "profile index out of range");
-    const ProfEntry& p = h->prof[i];
-    if (name && name_len > 0) snprintf(name, name_len, "%s", p.name.c_str());
-    if (launches) *launches = p.launches;
-    if (total_ms) *total_ms = p.ms;
-    if (flops) *flops = p.flops;
-    return DG_OK;
-}
-int dg_profile_reset(dg_handle* h) {
-    if (!h) return fail(DG_E_INVALID, "null handle");
-    prof_collect(h);
-    h->prof.clear();
-    h->prof_index.clear();
-    return DG_OK;
-}
-
-int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n) {
-    if (!h || !what || !dst) return fail(DG_E_INVALID, "null argument");
-    const std::string w(what);
-    const float* src = nullptr;
-    int64_t avail = 0;
-    if (w == "z") { src = h->z; avail = h->cap_rows * h->latent; }
-    else if (w == "m") { src = h->m; avail = h->cap_rows * h->latent; }
-    else if (w == "loss") { src = h->loss; avail = h->cap_rows; }
-    else if (w == "y") { src = h->y; avail = h->cap_rows * h->P; }
-    else if (w == "part") { src = h->part; avail = h->cap_rows * h->nsplit * h->latent; }
-#ifdef DG_MEASURE
-    else if (w == "job_trace" && h->d_job_trace) { src = reinterpret_cast<const float*>(h->d_job_trace); avail = (int64_t)kJobTraceCap * 4 * 2; }
-    else if (w == "tail_trace" && h->d_tail_trace) { src = reinterpret_cast<const float*>(h->d_tail_trace); avail = 4096 * 8 * 2; }
-#endif
-    else if (w.size() == 4 && w.compare(0, 3, "act") == 0) {
-        const int d = w[3] - '0';
-        if (d >= 0 && d < (int)h->act.size()) { src = h->act[d]; avail = h->cap_rows * h->act_row[d]; }
-        if (src && frag_on(h) && d + 1 < (int)h->act.size()) {
-            // the fragment-order path keeps this activation in fragment order: hand it over as NHWC rows
-            const int64_t cnt = n < avail ? n : avail;
-            const int64_t rows = (cnt + h->act_row[d] - 1) / h->act_row[d];
-            float* tmp = nullptr;
-            HIP_TRY(hipMalloc(&tmp, (size_t)rows * h->act_row[d] * sizeof(float)));
-            dg::launch_unfrag(h->actf[d], tmp, rows, h->act_row[d], nullptr);
-            hipError_t e = hipMemcpy(dst, tmp, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice);
-            (void)hipFree(tmp);
-            if (e != hipSuccess) return fail(DG_E_HIP, "hipMemcpy: %s", hipGetErrorString(e));
-            return cnt;
-        }
-    }
-    if (!src) return fail(DG_E_INVALID, "unknown buffer '%s'", what);
-    const int64_t cnt = n < avail ? n : avail;
-    HIP_TRY(hipMemcpy(dst, src, (size_t)cnt * sizeof(float), hipMemcpyDeviceToDevice));
-    return cnt;
-}
-
-static int set_option(dg_handle* h, const char* key, const char* value);
-
-int dg_set_option(dg_handle* h, const char* key, const char* value) {
-    if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
-    const int rc = set_option(h, key, value);
-    if (rc == DG_OK) ++h->list_epoch;    // an accepted option: captured loops are rebuilt on their next use (a refused one changes nothing)
-    return rc;
-}
-
-static int set_option(dg_handle* h, const char* key, const char* value) {
-    const std::string k(key);
-    if (k == "two_streams") {
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
-        if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
-        drop_job_lists(h);                     // a list's K-pair scratch is sized by the number of groups that may launch it at once
-        return DG_OK;
-    }
-    if (k == "lr_schedule") {
-        const std::string v(value);
-        if (v != "constant" && v != "intended") return fail(DG_E_INVALID, "lr_schedule: 'constant' or 'intended'");
-        h->lr_intended = v == "intended";
-        return DG_OK;
-    }
-    if (k == "two_stream_min_rows") {
-        h->two_stream_min_rows = atoi(value);
-        return DG_OK;
-    }
-    if (k == "graph_max_rows") {         // call shapes of at most this many latent rows replay a captured graph of the loop; 0 = never
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->graph_max_rows = atoi(value) > 0 ? atoi(value) : 0;
-        h->graph_broken = false;
-        drop_graphs(h);
-        free_workspace(h);               // the staging copy of the images is sized by this option
-        return DG_OK;
-    }
-    if (k == "update_fold") {            // 1 = the momentum update rides in the Linear backward launch (needs latent_turn)
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->update_fold = atoi(value) != 0;
-        return DG_OK;
-    }
-    if (k == "bn_fused") {               // 1 = Batchnorm forward statistics from the GEMM epilogue (default), 0 = a separate pass
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->bn_fused = atoi(value) != 0;
-        drop_job_lists(h);
-        return rebuild_plans(h);
-    }
-    if (k == "frag_path") {              // 1 = fragment-order forward path (dg_fgemm.hip; default), 0 = every GEMM on dg_gemm.hip
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->frag_path = atoi(value) != 0;
-        free_workspace(h);               // the fragment-order buffers exist only with it
-        drop_job_lists(h);               // (the backward layers' lists were timed with the other epilogue)
-        return DG_OK;
-    }
-    if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->latent_turn = atoi(value) != 0;
-        ++h->list_epoch;
-        return DG_OK;                    // job lists the other setting needs are built by the next prepare / call
-    }
-    if (k == "lin_groups_fwd" || k == "lin_groups_bwd") {
-        const int v = atoi(value);
-        if (v < 0 || v > 4096) return fail(DG_E_INVALID, "%s: 0 (auto) .. 4096", key);
-        (k == "lin_groups_fwd" ? h->lin_groups_fwd : h->lin_groups_bwd) = v;
-        ++h->list_epoch;
-        return DG_OK;
-    }
-    if (k == "tail_pipe") {
-        h->tail_pipe = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_pipe_version") {
-        if (atoi(value) < 1 || atoi(value) > 3) return fail(DG_E_INVALID, "tail_pipe_version: 1, 2 or 3");
-#ifndef DG_MEASURE
-        if (atoi(value) == 2) return fail(DG_E_INVALID, "tail_pipe_version = 2 (the superseded second-generation kernel) needs the measurement build");
-#endif
-        h->tail_pipe_version = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_fwd_split") {
-        h->tail_fwd_split = atoi(value) > 0 ? atoi(value) : 0;
-        return DG_OK;
-    }
-    if (k == "tail_bwd_persist") {
-#ifndef DG_MEASURE
-        if (atoi(value) <= 0) return fail(DG_E_INVALID, "tail_bwd_persist = 0 (the per-band backward kernel) needs the measurement build");
-#endif
-        h->tail_bwd_persist = atoi(value);
-        return DG_OK;
-    }
-    if (k == "jobs.slack" || k == "jobs.slots0" || k == "jobs.slots1" || k == "jobs.rate0" || k == "jobs.rate1" ||
-        k == "jobs.rate2" || k == "jobs.fixed_us" || k == "jobs.min_level" || k == "jobs.tune" || k == "jobs.xcd_head" || k == "jobs.taper" ||
-        k == "jobs.taper_tune" || k == "jobs.prio" || k == "jobs.balance" || k == "jobs.spread" || k == "jobs.pair_kernel") {
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        const double v = atof(value);
-        if (k == "jobs.slack") h->job_slack = v;
-        else if (k == "jobs.slots0") h->job_slots_per_cu[0][0] = (int)v > 0 ? (int)v : 1;
-        else if (k == "jobs.slots1") h->job_slots_per_cu[1][0] = (int)v > 0 ? (int)v : 1;
-        else if (k == "jobs.min_level") h->job_min_level = (int)v;
-        else if (k == "jobs.tune") h->job_tune = v != 0.0;
-        else if (k == "jobs.xcd_head") h->job_xcd_head = v;
-        else if (k == "jobs.taper") h->job_model.taper = v;
-        else if (k == "jobs.taper_tune") h->job_taper_tune = v != 0.0;
-        else if (k == "jobs.balance") h->job_balance = v != 0.0;
-        else if (k == "jobs.pair_kernel") h->job_pair_kernel = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
-        else if (k == "jobs.spread") h->job_spread = v != 0.0;
-        else if (k == "jobs.prio") h->job_prio = (int)v < 0 ? 0 : ((int)v > 2 ? 2 : (int)v);
-        else if (k == "jobs.fixed_us") { for (auto& f : h->job_model.fixed_us) for (double& x : f) x = v; }
-        else { for (auto& r : h->job_model.rate) r[k.back() - '0'] = v > 0 ? v : 1.0; }
-        drop_job_lists(h);
-        return DG_OK;
-    }
-    // ---- measurement options: the kernels behind them exist only in the -DDG_MEASURE build of the library
-    if (k == "tail_trace" || k == "tail_fwd16" || k == "tail_bwd_bands" || k == "tail_prio" || k == "tail_dbg" || k == "job_trace") {
-#ifdef DG_MEASURE
-    if (k == "tail_trace") {     // read back with dg_debug_read("tail_trace") (int64 pairs viewed as floats)
-        HIP_TRY(hipSetDevice(h->device));
-        if (atoi(value)) {
-            if (!h->d_tail_trace) HIP_TRY(hipMalloc(&h->d_tail_trace, 4096 * 8 * sizeof(long long)));
-            HIP_TRY(hipMemset(h->d_tail_trace, 0, 4096 * 8 * sizeof(long long)));
-        } else if (h->d_tail_trace) {
-            (void)hipFree(h->d_tail_trace);
-            h->d_tail_trace = nullptr;
-        }
-        return DG_OK;
-    }
-    if (k == "tail_fwd16") {
-        h->tail_fwd16 = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_bwd_bands") {
-        h->tail_bwd_bands = atoi(value);
-        return DG_OK;
-    }
-    if (k == "tail_prio") {
-        const int v = atoi(value);
-        if (v < 0 || v > 3) return fail(DG_E_INVALID, "%s: 0..3", key);
-        h->tail_prio = v;
-        return DG_OK;
-    }
-    if (k == "tail_dbg") {
-        h->tail_dbg = atoi(value);
-        return DG_OK;
-    }
-    if (k == "job_trace") {      // value = op name ("F2"); read back with dg_debug_read("job_trace") (int64 viewed as floats)
-        HIP_TRY(hipSetDevice(h->device));
-        if (!h->d_job_trace) HIP_TRY(hipMalloc(&h->d_job_trace, (size_t)kJobTraceCap * 4 * sizeof(long long)));
-        HIP_TRY(hipMemset(h->d_job_trace, 0, (size_t)kJobTraceCap * 4 * sizeof(long long)));
-        h->job_trace_op = value;
-        return DG_OK;
-    }
-#else
-        return fail(DG_E_INVALID, "option '%s' needs the measurement build of the library (libdefensegan_hip_measure.so, -DDG_MEASURE)", key);
-#endif
-    }
-    if (k == "debug.poison_pair_counters") {
-        // test hook (tests/test_gpu_variants.py): leaves every K-pair arrival counter of every list at `value`, the state a launch
-        // that died between the two arrivals of a pair would leave behind.  The next call must not care.
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        int n = 0;
-        std::vector<GemmOp*> ops = {&h->F1, &h->B1};
-        for (auto& op : h->Fd) ops.push_back(&op);
-        for (auto& op : h->Bd) ops.push_back(&op);
-        for (GemmOp* op : ops)
-            for (auto& jl : op->jobs) {
-                if (!jl.d_pair_count || jl.pair_copies <= 0) continue;
-                const std::vector<unsigned> v(jl.pair_count_stride * (size_t)jl.pair_copies, (unsigned)atoi(value));
-                HIP_TRY(hipMemcpy(jl.d_pair_count, v.data(), v.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-                ++n;
-            }
-        if (!n) return fail(DG_E_STATE, "debug.poison_pair_counters: no prepared job list holds K-pair jobs");
-        return DG_OK;
-    }
-    if (k == "nsplit") {
-        const int v = atoi(value);
-        if (v < 1 || v > 64 || (h->lin_out / v) % 32 || h->lin_out % v) return fail(DG_E_INVALID, "nsplit must divide lin_out into multiples of 32");
-        HIP_TRY(hipSetDevice(h->device));
-        HIP_TRY(hipDeviceSynchronize());
-        h->nsplit = v;
-        free_workspace(h);
-        const int rcp = build_lin_packs(h);
-        if (rcp) return rcp;
-        return rebuild_plans(h);
-    }
-    return fail(DG_E_INVALID, "unknown option '%s'", key);
 }
 
 }  // extern "C"
