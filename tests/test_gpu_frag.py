@@ -70,7 +70,8 @@ def test_projection_matches_and_rows_are_batch_independent(arch, B, R):
     d1 = {k: _np(v) for k, v in g1.reconstruct(x, z_init_val=z0, return_details=True).items()}
     d0 = {k: _np(v) for k, v in g0.reconstruct(x, z_init_val=z0, return_details=True).items()}
     np.testing.assert_allclose(d1["loss"], d0["loss"], rtol=2e-4)
-    assert np.abs(d1["rec"] - d0["rec"]).max() < 3e-3       # (three lr = 10 steps on adversarial targets amplify the rounding)
+    # (three GD steps on adversarial targets amplify the rounding; CelebA's tanh images span [-1, 1] and its loop is the touchier one)
+    assert np.abs(d1["rec"] - d0["rec"]).max() < (3e-3 if arch == "mnist" else 3e-2)
     assert (d1["idx"] == d0["idx"]).mean() >= 0.9
     # the same images as part of a smaller call: bit-identical rows (the K split is a constant of the tap class)
     h = B // 2

@@ -32,9 +32,10 @@ def _kit():
 
 def test_the_kit_generates_exactly_the_arrays_of_synth():
     kit = _kit()
-    for name, arch, wseed, gain, bias_range, B, R, adv, zseed in kit.CASES:
-        w, names = kit.make_weights(arch, wseed, gain, bias_range)
-        want = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=bias_range)
+    assert {c[0] for c in kit.CASES if c[9]} == {"mnist_bn", "celeba_bn"} and any(c[1] == "celeba" and not c[9] for c in kit.CASES)
+    for name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn in kit.CASES:
+        w, names = kit.make_weights(arch, wseed, gain, bias_range, use_bn)
+        want = synth.make_weights(arch, seed=wseed, gain=gain, bias_range=bias_range, use_bn=use_bn, bn_jitter=kit.BN_JITTER if use_bn else 0.0)
         assert sorted(names) == sorted(want), name
         for k in names:
             assert w[k].dtype == np.float32 and np.array_equal(w[k], want[k]), (name, k)
@@ -61,17 +62,18 @@ def _case(path):
     f = np.load(path)
     name = os.path.basename(path)[3:-4]
     spec = [c for c in kit.CASES if c[0] == name][0]
-    w, _ = kit.make_weights(spec[1], spec[2], spec[3], spec[4])
+    w, _ = kit.make_weights(spec[1], spec[2], spec[3], spec[4], spec[9])
     return f, spec, w
 
 
 NO_FIXTURES = ("no TensorFlow fixtures committed: run `python2 tools/make_tf_fixtures.py --reference <checkout of kabkabm/defensegan> "
-               "--out tests/golden` on a Python-2.7 / TensorFlow-1.7 machine (the build image has neither)")
+               "--out tests/golden` on a Python-2.7 / TensorFlow-1.7 machine (the build image has neither); one run pins the three "
+               "regimes -- no Batchnorm, USE_BN True, CelebA -- and the checkpoint reader")
 
 
 def _compare(f, spec, reconstruct, tol_scale):
     """reconstruct(x, z0, R, L) -> dict(rec [B..], idx [B], loss [B*R], rows [B*R..]) against the reference's outputs."""
-    name, arch, wseed, gain, bias_range, B, R, adv, zseed = spec
+    name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn = spec
     x, z0 = f["x"], f["z0"]
     for L in [int(v) for v in f["iters"]]:
         got = reconstruct(x, z0, R, L)
@@ -101,9 +103,9 @@ def test_oracle_against_the_reference_run_under_tensorflow(path):
     f, spec, w = _case(path)
 
     def rec(x, z0, R, L):
-        out = O.reconstruct(w, x, z0, R, L, lr=10.0, momentum=0.7, arch=spec[1], dtype=np.float64)
-        # every restart's G(z_{L-1}): the R = 1 call on the tiled images
-        tiled = O.reconstruct(w, np.repeat(x, R, axis=0), z0, 1, L, lr=10.0, momentum=0.7, arch=spec[1], dtype=np.float64)
+        out = O.reconstruct(w, x, z0, R, L, lr=10.0, momentum=0.7, arch=spec[1], dtype=np.float64, use_bn=bool(spec[9]))
+        # every restart's G(z_{L-1}): the R = 1 call on the tiled images (the same B * R rows: the same batch statistics)
+        tiled = O.reconstruct(w, np.repeat(x, R, axis=0), z0, 1, L, lr=10.0, momentum=0.7, arch=spec[1], dtype=np.float64, use_bn=bool(spec[9]))
         return {"rec": out["rec"], "idx": out["idx"], "loss": out["loss"], "rows": tiled["rec"]}
     _compare(f, spec, rec, tol_scale=1.0)
 
@@ -115,13 +117,13 @@ def test_engine_against_the_reference_run_under_tensorflow(path):
         pytest.skip(NO_FIXTURES)
     from defensegan_amd.gan import dataset_gan_dict
     f, spec, w = _case(path)
-    name, arch, wseed, gain, bias_range, B, R, adv, zseed = spec
+    name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn = spec
 
     def rec(x, z0, R_, L):
-        g = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": 128, "NET_DIM": 64}, test_mode=True, rec_rr=R_, rec_iters=L, rec_lr=10.0)
+        g = dataset_gan_dict[arch](cfg={"USE_BN": bool(use_bn), "LATENT_DIM": 128, "NET_DIM": 64}, test_mode=True, rec_rr=R_, rec_iters=L, rec_lr=10.0)
         assert g.set_weights(w) == []
         d = g.reconstruct(x, z_init_val=z0, return_details=True)
-        g1 = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": 128, "NET_DIM": 64}, test_mode=True, rec_rr=1, rec_iters=L, rec_lr=10.0)
+        g1 = dataset_gan_dict[arch](cfg={"USE_BN": bool(use_bn), "LATENT_DIM": 128, "NET_DIM": 64}, test_mode=True, rec_rr=1, rec_iters=L, rec_lr=10.0)
         assert g1.set_weights(w) == []
         rows = g1.reconstruct(np.repeat(x, R_, axis=0), z_init_val=z0)
         return {"rec": np.asarray(d["rec"]), "idx": np.asarray(d["idx"]), "loss": np.asarray(d["loss"]), "rows": np.asarray(rows)}
@@ -149,7 +151,7 @@ def validate_fixture(path):
     name = os.path.basename(path)[3:-4]
     specs = [c for c in kit.CASES if c[0] == name]
     assert specs, "%s: no case '%s' in tools/make_tf_fixtures.py CASES" % (path, name)
-    _, arch, wseed, gain, bias_range, B, R, adv, zseed = specs[0]
+    _, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn = specs[0]
     try:
         f = np.load(path)
         files = set(f.files)
@@ -185,7 +187,7 @@ def test_a_malformed_fixture_fails_instead_of_skipping(tmp_path):
     """The validator the committed fixtures go through rejects: an unknown case name, a truncated file, missing arrays, a z0
     that is not the kit's draw -- each with an AssertionError (a failure), never a skip."""
     kit = _kit()
-    name, arch, wseed, gain, bias_range, B, R, adv, zseed = kit.CASES[0]
+    name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn = kit.CASES[0]
     zt, z0 = kit.make_latents(zseed, B, R)
     P = int(np.prod(kit.image_dim(arch)))
     good = {"x": np.zeros([B] + kit.image_dim(arch), np.float32), "z0": z0, "iters": np.array([1]),
@@ -262,3 +264,31 @@ def test_the_kit_is_python_2_7_syntax():
             if tok.type == tokenize.OP and tok.string in ("->", ":=", "@="):
                 bad.append((tok.string, tok.start[0]))
     assert not bad, bad
+
+
+def test_the_batchnorm_case_compares_like_the_others_on_a_stand_in_fixture():
+    """The USE_BN cases of the kit exercise two things the others do not: Batchnorm parameters in the weight stream, and the fact
+    that the R = 1 call on the R-times tiled images (``rows_L``) sees the SAME B * R rows -- hence the same batch statistics
+    (tflib/ops/batchnorm.py:80-93) -- as the rec_rr = R call.  No TensorFlow here, so the comparison code is run on a STAND-IN
+    fixture made by the float32 oracle in the kit's format (this checks the plumbing, not the reference: parity stays unpinned)."""
+    from oracle import defensegan_oracle as O
+    kit = _kit()
+    spec = [c for c in kit.CASES if c[0] == "mnist_bn"][0]
+    name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn = spec
+    w, _ = kit.make_weights(arch, wseed, gain, bias_range, use_bn)
+    zt, z0 = kit.make_latents(zseed, B, R)
+    x = O.generator_forward(w, np.repeat(zt, R, axis=0), arch, True)[0][::R].astype(np.float32)      # any in-range images do
+    f = {"x": x, "z0": z0, "iters": np.array([1, 3])}
+    for L in (1, 3):
+        o = O.reconstruct(w, x, z0, R, L, lr=10.0, momentum=0.7, arch=arch, dtype=np.float32, use_bn=True)
+        t = O.reconstruct(w, np.repeat(x, R, axis=0), z0, 1, L, lr=10.0, momentum=0.7, arch=arch, dtype=np.float32, use_bn=True)
+        rows = t["rec"].reshape(B * R, -1).astype(np.float64)
+        loss = ((rows - np.repeat(x.reshape(B, -1).astype(np.float64), R, axis=0)) ** 2).mean(axis=1)
+        f.update({"rec_%d" % L: o["rec"], "rows_%d" % L: t["rec"], "loss_%d" % L: loss, "idx_%d" % L: loss.reshape(B, R).argmin(axis=1)})
+        assert np.allclose(o["loss"], loss, rtol=1e-4)            # the tiled call's rows ARE the restarts of the rec_rr = R call
+
+    def rec(x_, z0_, R_, L):
+        out = O.reconstruct(w, x_, z0_, R_, L, lr=10.0, momentum=0.7, arch=arch, dtype=np.float64, use_bn=True)
+        tiled = O.reconstruct(w, np.repeat(x_, R_, axis=0), z0_, 1, L, lr=10.0, momentum=0.7, arch=arch, dtype=np.float64, use_bn=True)
+        return {"rec": out["rec"], "idx": out["idx"], "loss": out["loss"], "rows": tiled["rec"]}
+    _compare(f, spec, rec, tol_scale=1.0)

@@ -32,14 +32,20 @@ import sys
 
 import numpy as np
 
-# (name, arch, wseed, gain, bias_range, B, R, adversarial, zseed): B*R rows per case; B is also the reference's batch_size,
-# which must be divisible by rec_rr (models/gan.py:101-104)
+# (name, arch, wseed, gain, bias_range, B, R, adversarial, zseed, use_bn): B*R rows per case; B is also the reference's
+# batch_size, which must be divisible by rec_rr (models/gan.py:101-104).  The three regimes of the path in ONE run: no Batchnorm
+# (the shipped configs, default.yml:3), USE_BN True on both architectures (batch statistics at inference, the `else` branch of
+# tflib/ops/batchnorm.py:80-93 -- the B*R rows of a call share their statistics, so these cases also pin WHICH rows those are),
+# and the CelebA generator; every case also leaves a tf.train.Saver checkpoint for the TensorFlow-free reader.
 CASES = [
-    ("mnist_clean", "mnist", 1234, 2.0, 0.1, 6, 3, False, 21),
-    ("mnist_adv", "mnist", 1234, 3.0, 0.1, 4, 2, True, 22),
-    ("fmnist_clean", "f-mnist", 4321, 2.0, 0.0, 4, 4, False, 23),
-    ("celeba_clean", "celeba", 1234, 2.0, 0.1, 2, 2, False, 24),
+    ("mnist_clean", "mnist", 1234, 2.0, 0.1, 6, 3, False, 21, False),
+    ("mnist_adv", "mnist", 1234, 3.0, 0.1, 4, 2, True, 22, False),
+    ("fmnist_clean", "f-mnist", 4321, 2.0, 0.0, 4, 4, False, 23, False),
+    ("celeba_clean", "celeba", 1234, 2.0, 0.1, 2, 2, False, 24, False),
+    ("mnist_bn", "mnist", 1234, 2.0, 0.1, 6, 3, False, 25, True),
+    ("celeba_bn", "celeba", 1234, 2.0, 0.1, 2, 2, False, 26, True),
 ]
+BN_JITTER = 0.2
 LATENT, NET_DIM = 128, 64
 
 
@@ -60,9 +66,16 @@ def _uniform(rs, stdev, shape):
     return rs.uniform(low=-lim, high=lim, size=shape).astype(np.float32)
 
 
-def make_weights(arch, seed, gain, bias_range):
+def bn_layers(arch):
+    """(name, channels) of the generator's Batchnorm layers in registry order: BN1 over the 4096 Linear features (axes [0]),
+    BN2 / BN3 per channel of Generator.2 / .3 (axes [0, 1, 2]); models/dataset_models.py:44-65, 135-156."""
+    return [("Generator.BN1", 4 * 4 * 4 * NET_DIM), ("Generator.BN2", 2 * NET_DIM), ("Generator.BN3", NET_DIM)]
+
+
+def make_weights(arch, seed, gain, bias_range, use_bn=False):
     """tflib initialisers (tflib/ops/linear.py:55-60 glorot, tflib/ops/deconv2d.py:46-76 he) x gain, drawn in layer order from
-    RandomState(seed), biases after all filters -- the same stream as defensegan_amd/synth.py:make_weights (use_bn False)."""
+    RandomState(seed), biases after all filters, then (use_bn) scale = 1 + U(+-0.2) and offset = U(+-0.2) per Batchnorm layer --
+    the same stream as defensegan_amd/synth.py:make_weights(..., use_bn, bn_jitter=0.2)."""
     rs = np.random.RandomState(seed)
     lin_out = 4 * 4 * 4 * NET_DIM
     w = {}
@@ -76,6 +89,11 @@ def make_weights(arch, seed, gain, bias_range):
     for name, shp in bias_shapes:
         w[name] = rs.uniform(-bias_range, bias_range, size=shp).astype(np.float32) if bias_range > 0 else np.zeros(shp, np.float32)
         names.append(name)
+    if use_bn:
+        for name, c in bn_layers(arch):
+            w[name + ".scale"] = (np.ones((c,), np.float32) + rs.uniform(-BN_JITTER, BN_JITTER, size=(c,)).astype(np.float32)).astype(np.float32)
+            w[name + ".offset"] = rs.uniform(-BN_JITTER, BN_JITTER, size=(c,)).astype(np.float32)
+            names += [name + ".scale", name + ".offset"]
     return w, names
 
 
@@ -102,8 +120,8 @@ def digest(arrs):
 
 def self_check():
     out = {}
-    for name, arch, wseed, gain, bias_range, B, R, adv, zseed in CASES:
-        w, names = make_weights(arch, wseed, gain, bias_range)
+    for name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn in CASES:
+        w, names = make_weights(arch, wseed, gain, bias_range, use_bn)
         zt, z0 = make_latents(zseed, B, R)
         out[name] = {"weights": digest([w[k] for k in names]), "z_true": digest([zt]), "z0": digest([z0]),
                      "noise": digest([sign_noise(zseed, [B] + image_dim(arch))])}
@@ -116,13 +134,13 @@ def run_reference(ref_root, out_dir, iters):
     import tflib
     from models import gan as ref_gan
 
-    for name, arch, wseed, gain, bias_range, B, R, adv, zseed in CASES:
-        w, names = make_weights(arch, wseed, gain, bias_range)
+    for name, arch, wseed, gain, bias_range, B, R, adv, zseed, use_bn in CASES:
+        w, names = make_weights(arch, wseed, gain, bias_range, use_bn)
         zt, z0 = make_latents(zseed, B, R)
         dim = image_dim(arch)
         lo = -1.0 if arch == "celeba" else 0.0
         result = {"arch": arch, "wseed": wseed, "gain": gain, "bias_range": bias_range, "R": R, "lr": 10.0, "momentum": 0.7,
-                  "z0": z0, "iters": np.asarray(iters)}
+                  "z0": z0, "iters": np.asarray(iters), "use_bn": int(use_bn)}
         x = None
         for pass_no, (rr, batch, tag) in enumerate([(R, B, "rec"), (1, B * R, "rows")]):
             for L in iters:
@@ -138,10 +156,10 @@ def run_reference(ref_root, out_dir, iters):
                 # AbstractModel.__init__ (models/base_model.py:29-84) reads cfg['cfg_path'] for its checkpoint directory and
                 # resolves every attribute it is not given from tf.app.flags / cfg (None otherwise): give it all of them
                 cfg = {"cfg_path": "experiments/cfgs/gans/%s.yml" % {"f-mnist": "fmnist"}.get(arch, arch), "DATASET_NAME": arch,
-                       "BATCH_SIZE": batch, "USE_BN": False, "LATENT_DIM": LATENT, "NET_DIM": NET_DIM, "REC_ITERS": L, "REC_RR": rr,
+                       "BATCH_SIZE": batch, "USE_BN": bool(use_bn), "LATENT_DIM": LATENT, "NET_DIM": NET_DIM, "REC_ITERS": L, "REC_RR": rr,
                        "REC_LR": 10.0, "IMAGE_DIM": dim}
                 model = NoData(cfg=cfg, test_mode=True, verbose=False, dataset_name=arch, batch_size=batch, test_batch_size=batch,
-                               use_bn=False, latent_dim=LATENT, net_dim=NET_DIM, rec_iters=L, rec_rr=rr, rec_lr=10.0, image_dim=dim,
+                               use_bn=bool(use_bn), latent_dim=LATENT, net_dim=NET_DIM, rec_iters=L, rec_rr=rr, rec_lr=10.0, image_dim=dim,
                                mode="gp-wgan", gradient_penalty_lambda=10.0, train_iters=1, critic_iters=5, input_transform_type=0,
                                debug=False, test_again=False, loss_type="l2", attribute="gender", tensorboard_log=False,
                                output_dir=os.path.join(out_dir, "tf_scratch"), num_gpus=1)
@@ -152,8 +170,8 @@ def run_reference(ref_root, out_dir, iters):
                 sess = model.sess
                 sess.run(tf.global_variables_initializer())
                 params = {v.name.split(":")[0].split("/")[-1]: v for v in model.generator_vars}
-                for k in names:
-                    sess.run(tf.assign(params[k], w[k]))
+                for k in names:               # (Batchnorm scale / offset are stored with the keep_dims shape of the moments)
+                    sess.run(tf.assign(params[k], w[k].reshape(params[k].shape.as_list())))
                 if x is None:
                     x = sess.run(g_op).reshape([B] + dim).astype(np.float32)
                     if adv:
