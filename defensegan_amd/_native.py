@@ -51,6 +51,10 @@ SYMBOLS = [
     ("dg_eval_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("dg_clf_input_gradient", _i, [_vp, _vp, _vp, _i, _vp, _vp]),
     ("dg_fgsm", _i, [_vp, _vp, _vp, _i, _f, _f, _f, _vp, _vp]),
+    ("dg_comm_unique_id", _i, [_vp]),
+    ("dg_comm_create", _i, [_i, _vp, _i, _i, C.POINTER(_vp)]),
+    ("dg_comm_destroy", _i, [_vp]),
+    ("dg_gather_eval", _i, [_vp, _vp, _vp, _i64, _vp]),
 ]
 
 _libs = {}

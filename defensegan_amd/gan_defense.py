@@ -215,21 +215,72 @@ def gather_shards(local_rows: np.ndarray, n_total: int, group=None, device=None)
     return np.concatenate([t[:k].cpu().numpy() for t, k in zip(out, sizes)])
 
 
+class EvalComm(object):
+    """An RCCL communicator behind the C ABI (include/defensegan_hip.h dg_comm_*): the evaluation's one all_gather WITHOUT
+    torch.distributed -- what a caller that is not a torch program (the reference is TensorFlow) binds.  One process per GPU:
+
+        uid = EvalComm.unique_id() on rank 0, carried to the other ranks by the caller (file, MPI, environment ...)
+        comm = EvalComm(nranks, uid, rank, device)
+        acc, roc = model_eval_gan_sharded(gan.reconstruct, clf, x, y, 50, rec_rr=10, comm=comm)
+    """
+
+    def __init__(self, nranks: int, unique_id: bytes, rank: int, device: int = 0):
+        import ctypes as C
+        from . import _native
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        self._lib = _native.load()
+        self._id = C.create_string_buffer(bytes(unique_id), 128)
+        h = C.c_void_p()
+        _native.check(self._lib.dg_comm_create(int(nranks), C.cast(self._id, C.c_void_p), int(rank), int(device), C.byref(h)))
+        self._h, self.rank, self.world, self.device = h, int(rank), int(nranks), int(device)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _native
+        buf = C.create_string_buffer(128)
+        _native.check(_native.load().dg_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def all_gather_i32(self, buf):
+        """[count] int32 device tensor of every rank -> [world * count] on every rank (asynchronous on torch's current stream)."""
+        import torch
+        from . import _native
+        assert buf.dtype == torch.int32 and buf.is_cuda and buf.is_contiguous()
+        out = torch.empty(self.world * buf.numel(), dtype=torch.int32, device=buf.device)
+        stream = torch.cuda.current_stream(buf.device).cuda_stream
+        _native.check(self._lib.dg_gather_eval(self._h, buf.data_ptr(), out.data_ptr(), buf.numel(), stream))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, batch_size: int, rec_rr: int = 1,
-                           group=None, device=None, n_total: Optional[int] = None, **kw):
+                           group=None, device=None, n_total: Optional[int] = None, comm: Optional["EvalComm"] = None, **kw):
     """Batch-sharded evaluation over a torch.distributed group: every rank evaluates its contiguous shard,
     then ONE all_gather (padded to the largest shard) assembles ``roc_info`` in global image order.
     Returns ``(accuracy, roc_info)`` identically on every rank.
 
     ``test_images`` / ``test_labels`` hold the WHOLE list (every rank slices its ``shard_range``), or -- when ``n_total`` is
-    given -- only this rank's shard of a list of ``n_total`` images (nothing but the shard needs to exist on a rank)."""
+    given -- only this rank's shard of a list of ``n_total`` images (nothing but the shard needs to exist on a rank).
+    ``comm``: an ``EvalComm`` (RCCL through the C ABI) instead of a torch.distributed group."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized():
+    if comm is None and (not dist.is_available() or not dist.is_initialized()):
         c, n, roc = model_eval_gan(reconstruct, classifier, test_images, test_labels, batch_size, rec_rr, **kw)
         return c / max(n, 1), roc
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = (comm.rank, comm.world) if comm is not None else (dist.get_rank(group), dist.get_world_size(group))
     presharded = n_total is not None
     if not presharded:
         n_total = len(test_images)
@@ -243,7 +294,8 @@ def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, ba
     c, n, roc = model_eval_gan(reconstruct, classifier, shard_x, shard_y, batch_size, rec_rr, first_image=s, as_tensors=True, **kw)
     cap = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
     if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+        device = (torch.device("cuda", comm.device) if comm is not None else
+                  torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu")
     # ONE message per rank, built where the results already are (the device, with an nccl group): int32
     # [count | labels (cap) | preds (cap) | diffs (cap, float32 bits)] -- exact, 12 bytes per image (15 KB per rank for the
     # 1250-image shards of BASELINE configs[4]), one all_gather, one copy back to the host
@@ -253,8 +305,11 @@ def model_eval_gan_sharded(reconstruct, classifier, test_images, test_labels, ba
     buf[1 + cap:1 + cap + n] = roc[1].to(device=device, dtype=torch.int32)
     if len(roc[2]):
         buf[1 + 2 * cap:1 + 2 * cap + n] = roc[2].to(device=device, dtype=torch.float32).view(torch.int32)
-    out = torch.empty(world * (1 + 3 * cap), dtype=torch.int32, device=device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    if comm is not None:
+        out = comm.all_gather_i32(buf)
+    else:
+        out = torch.empty(world * (1 + 3 * cap), dtype=torch.int32, device=device)
+        dist.all_gather_into_tensor(out, buf, group=group)
     t = out.view(world, 1 + 3 * cap).cpu().numpy()
     labels, preds, diffs = [], [], []
     for row in t:

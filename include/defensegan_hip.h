@@ -256,6 +256,22 @@ int dg_clf_input_gradient(dg_clf* h, const float* x, const int32_t* labels, int 
 int dg_fgsm(dg_clf* h, const float* x, const int32_t* labels, int B, float eps, float clip_min, float clip_max,
             float* x_adv, void* stream);
 
+/*
+ * The path's one collective: every rank projects and classifies its contiguous shard of the image list
+ * (no collective on the data path) and ONE all_gather assembles the evaluation message -- per rank `count` int32 words, e.g.
+ * [n | labels (cap) | preds (cap) | diffs (cap, float32 bits)] as defensegan_amd/gan_defense.py:model_eval_gan_sharded builds it
+ * (the reduction of /root/reference/utils/gan_defense.py:166-179 over ranks; the reference itself is single-process).  RCCL
+ * over xGMI, reachable WITHOUT torch.distributed: librccl.so is opened on first use.  Rank 0 draws a unique id, the caller
+ * carries its 128 bytes to the other ranks (file, MPI, environment), every rank creates its communicator -- one process per GPU.
+ * send [count], recv [nranks * count]: device pointers; asynchronous on `stream`.
+ */
+typedef struct { char internal[128]; } DgUniqueId;          /* = ncclUniqueId */
+typedef struct dg_comm dg_comm;
+int dg_comm_unique_id(DgUniqueId* id);
+int dg_comm_create(int nranks, const DgUniqueId* id, int rank, int device, dg_comm** out);
+int dg_comm_destroy(dg_comm* c);
+int dg_gather_eval(dg_comm* c, const int32_t* send, int32_t* recv, int64_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -186,3 +186,32 @@ def test_two_rank_worker_on_one_gpu_over_gloo():
     message and its single all_gather -- runs on the 1-GPU test box."""
     res = _run_two_ranks(DG_TEST_BACKEND="gloo", DG_TEST_SAME_DEVICE="1")
     assert [r["backend"] for r in res] == ["gloo", "gloo"]
+
+
+def test_the_collective_behind_the_c_abi_without_torch_distributed():
+    """dg_comm_* / dg_gather_eval (include/defensegan_hip.h): RCCL bound by the library itself.  A one-rank communicator here (one
+    GPU per box): the gathered message is the message, and model_eval_gan_sharded through it returns what the plain evaluation
+    returns; no torch.distributed group exists in this process."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from defensegan_amd import gan_defense as gd, network_builder as nb, synth
+    from tests.helpers import clean_targets, make_gan
+    assert not dist.is_initialized()
+    uid = gd.EvalComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = gd.EvalComm(1, uid, 0, device=0)
+    msg = torch.arange(1000, dtype=torch.int32, device="cuda:0")
+    got = comm.all_gather_i32(msg)
+    torch.cuda.synchronize()
+    assert torch.equal(got, msg)
+    R, L, N, BS = 4, 2, 70, 25
+    gan, p = make_gan("mnist", gain=2.0, bias_range=0.1, rec_rr=R, rec_iters=L)
+    x, _ = clean_targets(p, "mnist", N, seed=91)
+    y = (np.arange(N) * 3 % 10).astype(np.int64)
+    clf = nb.model_a()
+    clf.init_like_reference(seed=5)
+    acc, roc = gd.model_eval_gan_sharded(gan.reconstruct, clf, x, y, batch_size=BS, rec_rr=R, seed=3, comm=comm)
+    c1, n1, roc1 = gd.model_eval_gan(gan.reconstruct, clf, x, y, batch_size=BS, rec_rr=R, seed=3)
+    assert abs(acc - c1 / n1) < 1e-12 and all(np.array_equal(a, b) for a, b in zip(roc, roc1))
+    comm.close()
