@@ -173,6 +173,9 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
     }
 
     if (tron) tr[2] = (long long)__builtin_readcyclecounter();
+    // the reduction and the epilogue are VALU / LDS / store work: beside a co-resident wave's MFMA stream each of their instructions
+    // waited for a gap between two MFMAs (profiles/r06_frag_path_ab.txt: 8-13 us per tile); from here on this wave goes first
+    __builtin_amdgcn_s_setprio(3);
     // ---- K-split reduction through LDS: image = [TW][TN][4 quads][64 lanes][4 floats] (b128 per lane: conflict-free)
     constexpr int IMG_BYTES = TW * TN * 16 * 256;
     auto put = [&](char* img) {
@@ -221,25 +224,32 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
     // ---- epilogue (one wave per tile).  Accumulator (i, j): lane = (k-half fh, latent row r of the block), register 4 * q4 + e =
     // channel 32 * (cb0 + i) + 8 * q4 + 4 * fh + e: f32x4 pieces of 4 consecutive channels of one row.
     const int fh = lane >> 5, r = lane & 31;
+    f32x4 bv[TW][4];
 #pragma unroll
-    for (int i = 0; i < TW; ++i) {
-        const int ch0 = (jb.cb0 + i) * 32;
-        f32x4 bv[4];
+    for (int i = 0; i < TW; ++i)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-            bv[q4] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv[q4] = *reinterpret_cast<const f32x4*>(g.bias + ch0 + 8 * q4 + 4 * fh);
+            bv[i][q4] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU) bv[i][q4] = *reinterpret_cast<const f32x4*>(g.bias + (jb.cb0 + i) * 32 + 8 * q4 + 4 * fh);
         }
+    // NHWC output: the tile of one M block (32 rows x 64 channels) is transposed through this wave's own LDS slice (row pitch
+    // 272 B: the 16 lanes of a b128 write pass hit 16 different bank quads) so that 16 lanes store the 256 contiguous bytes of one
+    // row -- full 128-B lines; 16-B pieces scattered over 32 rows cost the single epilogue wave 13 us per tile (profiles/r06_frag_path_ab.txt)
+    constexpr int TPITCH = 32 * TW * 4 + 16;
+    char* const tslice = smem + wave * (32 * TPITCH);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (j >= nvalid) break;
+    for (int j = 0; j < TN; ++j) {
+        if (j >= nvalid) break;
+#pragma unroll
+        for (int i = 0; i < TW; ++i) {
+            const int ch0 = (jb.cb0 + i) * 32;
             unsigned bits = 0u;
             f32x4 v[4];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[i][j][q4 * 4 + e] + bv[q4][e];
+                    float t = acc[i][j][q4 * 4 + e] + bv[i][q4][e];
                     if constexpr (MODE == EPI_BIAS_RELU) {
                         bits |= (t > 0.f ? 1u : 0u) << (8 * q4 + 4 * fh + e);
                         t = t > 0.f ? t : 0.f;
@@ -255,15 +265,26 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
                     // (offset in the VGPR, immediate soffset: see dg_linear.hip frag_store -- the 16-byte-store data hazard)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[q4]), ro, voff + (o_pos[j] + ch0 + 8 * q4) * 128, 0, 0);
             } else {
-                float* orow = g.Out + ((long long)nb[j] * 32 + r) * g.out_rowstride + o_pos[j] + ch0 + 4 * fh;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(orow + 8 * q4) = v[q4];
+                for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<f32x4*>(tslice + r * TPITCH + (i * 32 + 8 * q4 + 4 * fh) * 4) = v[q4];
             }
             if constexpr (MODE == EPI_BIAS_RELU) {
                 if (g.gate_bits) {                   // ReluGrad gates of this layer's output, one bit per element (uniform branch)
                     bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
                     if (fh == 0) g.gate_bits[((long long)nb[j] * 32 + r) * g.gate_words + ((o_pos[j] + ch0) >> 5)] = bits;
                 }
+            }
+        }
+        if constexpr (!OUTFRAG) {
+            // 16 lanes per row (TW * 8 = 16 pieces of 16 B), 4 rows per instruction
+            constexpr int LPR = TW * 8;
+            const int rl = lane / LPR, cl = lane % LPR;
+            float* obase = g.Out + (long long)nb[j] * 32 * g.out_rowstride + o_pos[j] + jb.cb0 * 32 + cl * 4;
+#pragma unroll
+            for (int k = 0; k < 32 / (64 / LPR); ++k) {
+                const int row = k * (64 / LPR) + rl;
+                const f32x4 t = *reinterpret_cast<const f32x4*>(tslice + row * TPITCH + cl * 16);
+                *reinterpret_cast<f32x4*>(obase + (long long)row * g.out_rowstride) = t;
             }
         }
     }

@@ -707,7 +707,9 @@ bool frag_tap_grid(const BatchedPlan& p, int cls, TapGrid* g) {
 int frag_ksplit(const BatchedPlan& p, int cls) {
     const int nchunks = p.cls[(size_t)cls].nchunks;
     const int kc8 = p.kch / 8;
-    int ks = nchunks >= 24 ? 4 : (nchunks >= 12 ? 2 : 1);
+    // (thresholds measured in round 6, profiles/r06_frag_path_ab.txt: 24 / 12 lose 1 % to 40 / 20 on both workloads -- every split costs a
+    // reduction behind a barrier)
+    int ks = nchunks >= 40 ? 4 : (nchunks >= 20 ? 2 : 1);
     // a wave's part = n_taps * kc8 / ks k8-steps must be a multiple of the operand ring (4): ks <= kc8 / 4
     while (ks > 1 && ks > kc8 / 4) ks >>= 1;
     return ks;
