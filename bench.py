@@ -83,7 +83,7 @@ def traffic_for(workload, layers, B, R, tuning_id=None):
     return int(sum(vals) / len(vals)), "profiles/" + TRAFFIC_FILE
 
 
-PROFILE_ROUND = "r05"                  # profiles/<round>_*: the evidence collected on this build (tools/final_validation.sh)
+PROFILE_ROUND = "r06"                  # profiles/<round>_*: the evidence collected on this build (tools/final_validation.sh)
 TRAFFIC_FILE = PROFILE_ROUND + "_pmc_traffic.json"
 TUNING_FILE = PROFILE_ROUND + "_tuning_%s.txt"       # profiles/: the job-list choice of the profiling run, per architecture
 
@@ -356,7 +356,7 @@ def main():
                          "the PCIe-inclusive rate of the Python mirror (tagged io=host in the line; never the headline value)")
     ap.add_argument("--opt", action="append", default=[], help="engine option key=value (tuning)")
     ap.add_argument("--retune", action="store_true",
-                    help="time the job lists on this box instead of installing the committed choice (profiles/r05_tuning_<arch>.txt)")
+                    help="time the job lists on this box instead of installing the committed choice (profiles/r06_tuning_<arch>.txt)")
     ap.add_argument("--use_bn", action="store_true",
                     help="USE_BN: True variant of the generator (batch-statistics Batchnorm after every hidden layer, "
                          "tflib/ops/batchnorm.py:80-93); not a BASELINE config (the shipped cfgs have USE_BN: False)")

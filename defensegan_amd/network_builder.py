@@ -402,3 +402,17 @@ class FastGradientMethod(object):
             _native.check(_native.load().dg_fgsm(m._handle, t.data_ptr(), lab.data_ptr() if lab is not None else None,
                                                  int(t.shape[0]), float(eps), lo, hi, out.data_ptr(), stream))
         return out.cpu().numpy() if was_numpy else out
+
+
+def rand_fgsm_prestep(test_images, eps: float, alpha: float, min_val: float = 0.0, max_val: float = 1.0, rng=None):
+    """The ``rand`` half of ``--attack_type rand+fgsm`` (/root/reference/whitebox.py:191-195): one random sign step of size
+    ``alpha`` before the FGSM step, whose budget shrinks by it:
+
+        x' = clip(x + alpha * sign(N(0, 1)), min_val, 1),   eps' = eps - alpha
+
+    Returns ``(x', eps')``; feed both to ``FastGradientMethod.generate``.  ``rng``: a ``numpy.random.RandomState`` (the reference
+    draws from the global NumPy generator it seeded with [11, 24, 1990], whitebox.py:143-144)."""
+    rng = np.random if rng is None else rng
+    x = np.asarray(test_images, np.float32)
+    out = np.clip(x + np.float32(alpha) * np.sign(rng.randn(*x.shape)).astype(np.float32), min_val, max_val).astype(np.float32)
+    return out, float(eps) - float(alpha)

@@ -233,3 +233,14 @@ def test_whitebox_fgsm_through_the_defense_reproduces_the_reference():
     assert n == 10 and 0 <= c <= 10
     diff_op = ((adv - x) ** 2).reshape(10, -1).mean(axis=1)
     assert (diff_op[1:] == 0).all() and diff_op[0] > 0
+
+
+def test_rand_fgsm_prestep_is_the_reference_expression():
+    """whitebox.py:191-195: clip(x + alpha * sign(randn), min_val, 1) and eps - alpha, from the same generator state."""
+    from defensegan_amd import network_builder as nb
+    x = np.random.RandomState(0).uniform(-1, 1, size=(5, 8, 8, 3)).astype(np.float32)
+    got, eps = nb.rand_fgsm_prestep(x, eps=0.3, alpha=0.05, min_val=-1.0, rng=np.random.RandomState([11, 24, 1990]))
+    rs = np.random.RandomState([11, 24, 1990])
+    want = np.clip(x + 0.05 * np.sign(rs.randn(*x.shape)), -1.0, 1.0)
+    assert abs(eps - 0.25) < 1e-12 and got.dtype == np.float32 and np.allclose(got, want, atol=1e-7)
+    assert np.abs(got - x).max() <= 0.05 + 1e-6 and got.min() >= -1.0 and got.max() <= 1.0
