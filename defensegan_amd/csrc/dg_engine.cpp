@@ -225,8 +225,10 @@ int run_frag(dg_handle* h, GemmOp& op, int d, const float* A, float* Out, bool o
     a.mode = op.mode;
     a.out_frag = out_frag ? 1 : 0;
     a.n_jobs = fl->n_jobs;
+    a.wave_begin = fl->d_begin;
+    a.n_wgs = fl->n_wgs;
     char sym[64];
-    snprintf(sym, sizeof sym, "@fgemm_kernel<2, 4, %d, %s>", op.mode, out_frag ? "true" : "false");
+    snprintf(sym, sizeof sym, fl->d_begin ? "@fgemm_persist_kernel<2, 4, %d, %s>" : "@fgemm_kernel<2, 4, %d, %s>", op.mode, out_frag ? "true" : "false");
     {
         ProfScope ps(h, s, prof, op.name + sym, 2.0 * (double)op.bplan.macs_per_row * n_rows);
         dg::launch_fgemm(a, s);
@@ -419,7 +421,7 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
             float* Out = kind == 0 ? h->act[0] : kind == 1 ? h->act[d + 1] : kind == 2 ? h->act[d] : h->part;
             if (lin_stationary(h, op)) return (int)DG_OK;          // no job list: dg_linear.hip derives its grid from the row count
             if (kind == 1 && frag_on(h)) {                         // forward deconv on dg_fgemm.hip: its own kind of list, not timed
-                if (!get_frag_jobs(op, nr)) return fail(DG_E_NOMEM, "cannot build the fragment-order job list of layer %s for %d rows", op.name.c_str(), nr);
+                if (!get_frag_jobs(op, nr, h->frag_path >= 2 ? 2 * h->cu_count : 0)) return fail(DG_E_NOMEM, "cannot build the fragment-order job list of layer %s for %d rows", op.name.c_str(), nr);
                 return (int)DG_OK;
             }
             h->tune_gates = (kind == 2 && frag_on(h)) ? h->gate[(size_t)d] : nullptr;

@@ -86,6 +86,8 @@ struct JobList {
 struct FragList {
     int n_rows = 0, n_jobs = 0;
     dg::FragJob* d_jobs = nullptr;
+    int* d_begin = nullptr;        // persistent form (frag_path = 2): per-wave ranges of d_jobs, in the same allocation
+    int n_wgs = 0;
 };
 
 struct GemmOp {
@@ -311,7 +313,7 @@ int clear_pair_counters(dg_handle* h, int n_rows, hipStream_t s);
 const JobList* find_jobs(const GemmOp& op, int n_rows);
 const JobList* get_jobs(dg_handle* h, GemmOp& op, int n_rows, const float* A, float* Out, hipStream_t s);
 const FragList* find_frag_jobs(const GemmOp& op, int n_rows);
-const FragList* get_frag_jobs(GemmOp& op, int n_rows);
+const FragList* get_frag_jobs(GemmOp& op, int n_rows, int persist_wgs = 0);
 // ---- dg_engine.cpp
 bool lin_stationary(const dg_handle* h, const GemmOp& op);
 bool frag_on(const dg_handle* h);

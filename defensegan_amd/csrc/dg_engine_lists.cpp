@@ -430,18 +430,26 @@ const FragList* find_frag_jobs(const GemmOp& op, int n_rows) {
     return nullptr;
 }
 
-const FragList* get_frag_jobs(GemmOp& op, int n_rows) {
+const FragList* get_frag_jobs(GemmOp& op, int n_rows, int persist_wgs) {
     if (const FragList* have = find_frag_jobs(op, n_rows)) return have;
-    const std::vector<dg::FragJob> jobs = dg::build_frag_jobs(op.bplan, n_rows);
+    std::vector<int> begin;
+    const std::vector<dg::FragJob> jobs = persist_wgs > 0 ? dg::build_frag_tiles(op.bplan, n_rows, persist_wgs, &begin)
+                                                         : dg::build_frag_jobs(op.bplan, n_rows);
     if (jobs.empty()) return nullptr;
     FragList fl;
     fl.n_rows = n_rows;
     fl.n_jobs = (int)jobs.size();
-    if (hipMalloc(&fl.d_jobs, jobs.size() * sizeof(dg::FragJob)) != hipSuccess) return nullptr;
-    if (hipMemcpy(fl.d_jobs, jobs.data(), jobs.size() * sizeof(dg::FragJob), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(fl.d_jobs);
+    fl.n_wgs = persist_wgs;
+    const size_t jb = jobs.size() * sizeof(dg::FragJob), bb = begin.size() * sizeof(int);
+    char* base = nullptr;
+    if (hipMalloc(&base, jb + bb + 16) != hipSuccess) return nullptr;
+    fl.d_jobs = reinterpret_cast<dg::FragJob*>(base);
+    if (hipMemcpy(fl.d_jobs, jobs.data(), jb, hipMemcpyHostToDevice) != hipSuccess ||
+        (bb && hipMemcpy(base + jb, begin.data(), bb, hipMemcpyHostToDevice) != hipSuccess)) {
+        (void)hipFree(base);
         return nullptr;
     }
+    fl.d_begin = bb ? reinterpret_cast<int*>(base + jb) : nullptr;
     if (op.fjobs.size() >= 16) { (void)hipFree(op.fjobs.front().d_jobs); op.fjobs.erase(op.fjobs.begin()); }
     op.fjobs.push_back(fl);
     return &op.fjobs.back();

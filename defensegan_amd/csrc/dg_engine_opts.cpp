@@ -93,9 +93,13 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     if (k == "frag_path") {              // 1 = fragment-order forward path (dg_fgemm.hip; default), 0 = every GEMM on dg_gemm.hip
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
-        h->frag_path = atoi(value) != 0;
+        h->frag_path = atoi(value) < 0 ? 0 : (atoi(value) > 2 ? 2 : atoi(value));       // 2 = persistent waves (dg_fgemm.hip fgemm_persist_kernel)
         free_workspace(h);               // the fragment-order buffers exist only with it
         drop_job_lists(h);               // (the backward layers' lists were timed with the other epilogue)
+        for (GemmOp& op : h->Fd) {       // the two forms keep different fragment-order lists
+            for (auto& fl : op.fjobs) if (fl.d_jobs) (void)hipFree(fl.d_jobs);
+            op.fjobs.clear();
+        }
         return DG_OK;
     }
     if (k == "latent_turn") {            // 1 = weight-stationary Linear kernels (default), 0 = position-batched kernel

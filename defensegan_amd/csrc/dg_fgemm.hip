@@ -41,16 +41,15 @@ namespace {
 constexpr int SG_MFMA = 0x8, SG_VMEM_READ = 0x20;
 constexpr int FRING = 4;                  // k8-steps of operands in flight per wave
 
-template <int TW, int TN, int MODE, bool OUTFRAG>
-__global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // two accumulator images (K-split reduction)
-    const FragJob jb = g.jobs[blockIdx.x];
+// PERSIST: the record is ONE wave tile of this wave's own list (fgemm_persist_kernel): no K split, no other wave involved.
+template <int TW, int TN, int MODE, bool OUTFRAG, bool PERSIST>
+__device__ __forceinline__ void frag_body(const FragArgs& g, const FragJob jb, char* smem, int trace_slot) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ks = __builtin_amdgcn_readfirstlane(jb.ksplit);
+    const int ks = PERSIST ? 1 : __builtin_amdgcn_readfirstlane(jb.ksplit);
     const int q = wave & (ks - 1);                                   // K part of this wave
-    const int tile = ks == 4 ? 0 : (ks == 2 ? wave >> 1 : wave);     // wave tile inside the job
+    const int tile = PERSIST ? 0 : (ks == 4 ? 0 : (ks == 2 ? wave >> 1 : wave));     // wave tile inside the job
     int nvalid = jb.n_mblk - tile * TN;
     nvalid = nvalid > TN ? TN : nvalid;
     const bool active = nvalid > 0;
@@ -64,11 +63,12 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
     constexpr int dbg = 0;
 #endif
     if (tron) tr[0] = (long long)__builtin_readcyclecounter();
+    if constexpr (PERSIST) __builtin_amdgcn_s_setprio(0);            // (the previous tile of this wave ended at priority 3)
     auto dump = [&]() {
         if (!tron || lane != 0) return;
         unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        long long* t = DG_TRACE_PTR(g) + ((long long)blockIdx.x * 4 + wave) * 8;
+        long long* t = DG_TRACE_PTR(g) + (long long)trace_slot * 8;
         t[0] = tr[0]; t[1] = tr[1]; t[2] = tr[2]; t[3] = tr[3]; t[4] = (long long)__builtin_readcyclecounter(); t[5] = hwid; t[6] = (xcc & 15) | (ks << 8) | (q << 16); t[7] = jb.n_taps * (g.kch >> 3) / ks;
     };
     if (ks == 1 && !active) return;                                  // (no barrier below for ks == 1)
@@ -291,10 +291,35 @@ __global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
     dump();
 }
 
+template <int TW, int TN, int MODE, bool OUTFRAG>
+__global__ __launch_bounds__(256, 2) void fgemm_kernel(FragArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two accumulator images (K-split reduction) / epilogue slices
+    frag_body<TW, TN, MODE, OUTFRAG, false>(g, g.jobs[blockIdx.x], smem, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+}
+
+// Persistent form (engine option frag_path = 2): 2 workgroups per CU, every WAVE walks its own list of whole wave tiles
+// (dg_plan.h build_frag_tiles: longest-first bin packing of the layer's tiles over the wave slots, no tile split along K) -- no
+// dispatch granularity, no reduction, no barrier anywhere; a wave's turnover between two tiles is covered by the wave it shares
+// its SIMD with.
+template <int TW, int TN, int MODE, bool OUTFRAG>
+__global__ __launch_bounds__(256, 2) void fgemm_persist_kernel(FragArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // the waves' epilogue slices
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    const int t0 = g.wave_begin[gw], t1 = g.wave_begin[gw + 1];
+    for (int t = t0; t < t1; ++t) frag_body<TW, TN, MODE, OUTFRAG, true>(g, g.jobs[t], smem, t);
+}
+
 template <int MODE, bool OUTFRAG>
 void launch_mo(const FragArgs& a, hipStream_t s) {
     constexpr int TW = 2, TN = 4;
     const int lds = 2 * TW * TN * 16 * 256;
+    if (a.wave_begin) {
+        static PerDeviceOnce attrp;
+        if (attrp.need())
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fgemm_persist_kernel<TW, TN, MODE, OUTFRAG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((fgemm_persist_kernel<TW, TN, MODE, OUTFRAG>), dim3((unsigned)a.n_wgs), dim3(256), lds, s, a);
+        return;
+    }
     static PerDeviceOnce attr;
     if (attr.need())
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fgemm_kernel<TW, TN, MODE, OUTFRAG>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -106,6 +106,9 @@ struct FragArgs {
     int mode;                // EPI_BIAS_RELU / EPI_BIAS / EPI_STORE
     int out_frag;
     int n_jobs;
+    // persistent form: jobs = the wave tiles grouped by wave, wave w of workgroup b walks jobs[wave_begin[4 b + w] .. wave_begin[4 b + w + 1])
+    const int* wave_begin;   // nullptr = one workgroup per job record (fgemm_kernel)
+    int n_wgs;
 #ifdef DG_MEASURE
     int dbg;                 // timing experiments (env DG_FRAG_DBG): 1 = no epilogue, 2 = no K-split reduction
     long long* trace;        // [n_jobs * 4][8] per-wave cycle stamps (tools/frag_trace.py)

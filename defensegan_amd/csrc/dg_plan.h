@@ -175,5 +175,10 @@ int frag_ksplit(const BatchedPlan& p, int cls);
 bool frag_supported(const BatchedPlan& p);
 // Job list of one launch at n_rows latent rows (ceil(n_rows / 32) row blocks), longest jobs first.
 std::vector<FragJob> build_frag_jobs(const BatchedPlan& p, int n_rows);
+// The persistent form: every wave tile of the layer (4 M blocks x 64 channels, never split along K) assigned to one of
+// `n_wgs * 4` waves -- longest first into the lightest PAIR of waves that share a SIMD (wave w of workgroups b and b + n_wgs / 2: the
+// dispatcher hands workgroup i to CU i mod #CUs), then alternately to the pair's two waves -- and returned grouped by wave;
+// begin[k] .. begin[k + 1] = the records of wave k = 4 * workgroup + wave (begin has n_wgs * 4 + 1 entries).
+std::vector<FragJob> build_frag_tiles(const BatchedPlan& p, int n_rows, int n_wgs, std::vector<int>* begin);
 
 }  // namespace dg

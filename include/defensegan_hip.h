@@ -196,17 +196,26 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      default batch (500 rows: 780 vs 779 img/s), and on ROCm 7.2 a graph the CALLER captured of a call on the same
  *                      handle replays wrongly after an internal replay ran in between (tools/graph_interplay_repro.py) -- do not
  *                      combine the two on one handle
+ *   "frag_path"        1: the FORWARD deconvs run on the LDS-free fragment-order kernel (dg_fgemm.hip: both operands in MFMA fragment
+ *                      order, fetched straight into registers; the Linear forward writes fragment order, the backward GEMMs take
+ *                      their ReluGrad gates from one bit per element).  Agrees with the default path to float32 rounding (another
+ *                      fixed summation tree per tap class: a tile's K axis is split over 1 / 2 / 4 waves), rows stay independent of
+ *                      their batch.  Default 0: its loop is faster in isolation (147-149 vs 137-142 TFLOP/s) but the path is 2-10 %
+ *                      SLOWER at 1280 ... 12 500 rows (profiles/r06_frag_path_ab.txt).  Not with use_bn or two_streams
+ *   "debug.poison_pair_counters"   test hook: leaves every K-pair arrival counter of every prepared job list at `value` -- the state a
+ *                      launch that died between a pair's two arrivals would leave.  Every call clears the counters of the lists it
+ *                      launches, so the next call must not care (tests/test_gpu_variants.py)
  *   "tail_pipe"        MNIST tail: workgroups of the pipelined kernel (0 = fused per-row kernel)
  *   "tail_fwd_split"   CelebA forward tail (NET_DIM 64): workgroups of the role-split persistent kernel (default 512 = two per CU);
  *                      0 = the per-band kernel (celeba_tail_fwd16_kernel; same y and da6 bit for bit, the per-row loss to rounding)
  *   "tail_bwd_persist" CelebA backward tail: workgroups of the persistent kernel
  * Only in the measurement build of the library (same sources with -DDG_MEASURE -> libdefensegan_hip_measure.so; the product
- * library refuses them): "tail_fwd16" = 0 (32x32x2 CelebA forward tail), "tail_bwd_persist" = 0 + "tail_bwd_bands" (per-band
+ * library refuses them): "tail_pipe_version" = 2 (second-generation MNIST tail), "tail_fwd16" = 0 (32x32x2 CelebA forward tail), "tail_bwd_persist" = 0 + "tail_bwd_bands" (per-band
  * backward tail), "tail_trace", "tail_dbg", "tail_prio", "job_trace" (in-kernel phase traces and phase-removal switches, tools/)
  * Every job-list / launch-shape option leaves the results bit-identical (tests/test_gpu_variants.py): GEMM tiles are only
  * ever cut along M and N; along K only the classes of >= 80 K chunks, and those ALWAYS, in two fixed halves whose sums are added
  * once (K-pair jobs, dg_plan.h kPairMinChunks: a + b = b + a, so the arrival order does not show); "nsplit", "tail_fwd16" and
- * "bn_fused" change a summation order (agreement to rounding).
+ * "bn_fused" and "frag_path" change a summation order (agreement to rounding).
  */
 int dg_set_option(dg_handle* h, const char* key, const char* value);
 

@@ -12,6 +12,9 @@ from defensegan_amd import archs, synth
 pytestmark = pytest.mark.gpu
 
 
+FRAG_MODES = (1, 2)        # 1: one workgroup per job (K split over waves), 2: persistent waves walking their own tile lists (no K split)
+
+
 def _make(arch, frag, R=2, L=3, gain=2.0, seed=1234, lr=10.0):
     from defensegan_amd.gan import dataset_gan_dict
     gan = dataset_gan_dict[arch](cfg={"USE_BN": False, "LATENT_DIM": 128, "NET_DIM": 64}, test_mode=True,
@@ -26,11 +29,12 @@ def _np(v):
     return np.asarray(v.cpu().numpy() if hasattr(v, "cpu") else v)
 
 
+@pytest.mark.parametrize("frag", FRAG_MODES)
 @pytest.mark.parametrize("arch", ["mnist", "celeba"])
 @pytest.mark.parametrize("n", [1, 37, 64, 500])
-def test_activations_loss_and_gradient_match_the_position_batched_path(arch, n):
+def test_activations_loss_and_gradient_match_the_position_batched_path(arch, n, frag):
     a = archs.make_arch(arch)
-    g1, p = _make(arch, 1)
+    g1, p = _make(arch, frag)
     g0, _ = _make(arch, 0)
     rs = np.random.RandomState(n)
     z = (rs.standard_normal((n, 128)) * 0.15).astype(np.float32)
@@ -43,10 +47,10 @@ def test_activations_loss_and_gradient_match_the_position_batched_path(arch, n):
         scale = max(1.0, float(np.abs(a0).max()))
         assert np.abs(a1 - a0).max() <= 2e-6 * scale, (d, np.abs(a1 - a0).max(), scale)
         assert ((a1 > 0) == (a0 > 0)).mean() > 0.9999
-    np.testing.assert_allclose(y1, y0, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(y1, y0, rtol=0, atol=2e-5)            # (pre-activations of up to 1600 products, another summation tree)
     got = [_np(v) for v in g1.loss_grad(x, z)]
     ref = [_np(v) for v in g0.loss_grad(x, z)]
-    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(got[1], ref[1], rtol=1e-5)
     scale = np.abs(ref[2]).max()
     # rows whose ReLU gates differ between two equally valid summation orders are allowed to depart (a pre-activation within
@@ -56,12 +60,13 @@ def test_activations_loss_and_gradient_match_the_position_batched_path(arch, n):
     assert (err < 0.05).all(), err.max()
 
 
+@pytest.mark.parametrize("frag", FRAG_MODES)
 @pytest.mark.parametrize("arch,B,R", [("mnist", 50, 10), ("celeba", 13, 10)])
-def test_projection_matches_and_rows_are_batch_independent(arch, B, R):
+def test_projection_matches_and_rows_are_batch_independent(arch, B, R, frag):
     a = archs.make_arch(arch)
     # (CelebA at the reference's lr = 10 is chaotic from the first steps on -- DESIGN section 2 --: compared where the loop contracts)
     lr = 10.0 if arch == "mnist" else 2.0
-    g1, p = _make(arch, 1, R=R, L=3, lr=lr)
+    g1, p = _make(arch, frag, R=R, L=3, lr=lr)
     g0, _ = _make(arch, 0, R=R, L=3, lr=lr)
     rs = np.random.RandomState(5)
     x = _np(g0.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))

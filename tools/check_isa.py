@@ -60,7 +60,7 @@ def fgemm_loops(lines):
     """Per fgemm kernel: (name, MFMAs in the K loop, smallest vmcnt waited for inside it, branches inside it)."""
     out = []
     for name, body in kernels_of(lines):
-        if "fgemm_kernel" not in name:
+        if "fgemm_" not in name:
             continue
         # the K loop: the loop (header annotation .. its backward branch) that holds the MFMAs
         best = None
