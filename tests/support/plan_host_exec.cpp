@@ -1,5 +1,6 @@
 // TEST SUPPORT (never linked into the product library): executes a dg::LayerPlan with plain host
 // loops so the per-position tap tables can be checked against the oracle on a CPU-only box.
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -237,6 +238,67 @@ void dgp2_apply(void* h, const double* A, const double* W, const double* bias, d
             }
         }
     }
+}
+
+// ---- fragment-order lists (dg_fgemm.hip): build_frag_jobs / build_frag_tiles executed with host loops ------------------------------
+// n_wgs == 0: the per-job list; n_wgs > 0: the persistent form.  Addresses are formed the way the device forms them -- M block ->
+// (row block, position) by the record's magic multipliers, taps by the record's affine grid -- in the logical NHWC layout (the
+// fragment order is a permutation of the same elements).  info = n_jobs, supported, max ksplit, heaviest wave (K chunks), mean wave.
+int dgp2_frag_apply(void* h, int n_rows, int n_wgs, const double* A, const double* W, const double* bias, double* Out, int* touched,
+                    int mode, double* info) {
+    const Batched& b = *static_cast<Batched*>(h);
+    const dg::BatchedPlan& p = b.plan;
+    info[1] = dg::frag_supported(p) ? 1 : 0;
+    if (!dg::frag_supported(p)) return 0;
+    std::vector<int> begin;
+    std::vector<dg::FragJob> jobs = n_wgs > 0 ? dg::build_frag_tiles(p, n_rows, n_wgs, &begin) : dg::build_frag_jobs(p, n_rows);
+    info[0] = (double)jobs.size(); info[2] = 0; info[3] = 0; info[4] = 0;
+    if (n_wgs > 0) {
+        if ((int)begin.size() != n_wgs * 4 + 1 || begin.front() != 0 || begin.back() != (int)jobs.size()) return -1;
+        double tot = 0;
+        for (int w = 0; w < n_wgs * 4; ++w) {
+            if (begin[w + 1] < begin[w]) return -1;
+            double l = 0;
+            for (int i = begin[w]; i < begin[w + 1]; ++i) l += jobs[i].n_taps * (p.kch / 32) + 1.5;
+            info[3] = std::max(info[3], l);
+            tot += l;
+        }
+        info[4] = tot / (n_wgs * 4);
+    }
+    const int kc8 = p.kch / 8;
+    for (const dg::FragJob& jb : jobs) {
+        info[2] = std::max(info[2], (double)jb.ksplit);
+        if ((jb.n_taps * kc8) % (4 * jb.ksplit)) return -2;                  // a wave's K part is whole turns of the operand ring
+        for (int m = 0; m < jb.n_mblk; ++m) {
+            const unsigned mblk = (unsigned)(jb.mblk0 + m);
+            const int rb = (int)(((unsigned long long)(mblk << 1) * jb.s_magic) >> 32);
+            const int jj = (int)mblk - rb * jb.s;
+            const int jh = (int)(((unsigned long long)((unsigned)jj << 1) * jb.wc_magic) >> 32);
+            const int jw = jj - jh * jb.wc;
+            const int pa = jb.a_base + jh * jb.a_rs + jw * jb.a_cs, po = jb.o_base + jh * jb.o_rs + jw * jb.o_cs;
+            for (int r = 0; r < 32; ++r) {
+                const long long n = (long long)rb * 32 + r;
+                if (n >= n_rows) break;
+                for (int c = 0; c < 64; ++c) {
+                    const int col = jb.cb0 * 32 + c;
+                    double acc = 0.0;
+                    for (int t = 0; t < jb.n_taps; ++t) {
+                        const int u = (int)(((unsigned long long)((unsigned)t << 1) * jb.tap_nw_magic) >> 32), v = t - u * jb.tap_nw;
+                        const double* a = A + n * p.a_rowstride + pa + jb.a0 + u * jb.a_u + v * jb.a_v;
+                        const double* w = W + jb.w0 + u * jb.w_u + v * jb.w_v + (long long)col * p.w_rowstride;
+                        for (int k = 0; k < p.kch; ++k) acc += a[k] * w[k];
+                    }
+                    const long long o = n * p.out_rowstride + po + col;
+                    if (mode == 1 || mode == 2) acc += bias[col];
+                    if (mode == 2) acc = acc > 0 ? acc : 0;
+                    if (mode == 3) acc = Out[o] > 0 ? acc : 0;
+                    Out[o] = acc;
+                    touched[o] += 1;
+                }
+            }
+        }
+    }
+    return (int)jobs.size();
 }
 
 }  // extern "C"

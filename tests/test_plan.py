@@ -44,6 +44,7 @@ def lib():
                                      C.c_double, C.c_char_p, C.c_int]
     l.dgp2_rebuild_matches.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
     l.dgp2_job_pairs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    l.dgp2_frag_apply.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.POINTER(C.c_double)]
     l.dgp2_make_balanced.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
     l.dgp2_assign_priorities.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     l.dgp2_format_with_prio.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int]
@@ -752,3 +753,66 @@ def test_random_sweep_of_list_variants_covers_every_output_once_with_the_right_v
         np.testing.assert_allclose(out, want, rtol=1e-10, atol=1e-10, err_msg=str((draw, kind, h_in, e, cin, cout, bn, n_rows, cus, lvl)))
         lib.dgp2_free(h2); lib.dgp_free(h1)
     assert seen_pairs >= 2 and seen_balanced >= 3         # the sweep met K-pair lists and single-round balanced lists
+
+
+# ---------------------------------------------------------------------------------- fragment-order lists (dg_fgemm.hip)
+def apply_frag(lib, h2, n_rows, n_wgs, A, W, bias, out, mode):
+    A = np.ascontiguousarray(A, np.float64); W = np.ascontiguousarray(W, np.float64)
+    b = np.ascontiguousarray(bias, np.float64) if bias is not None else np.zeros(1)
+    touched = np.zeros(out.shape, np.int32)
+    info = (C.c_double * 5)()
+    rc = lib.dgp2_frag_apply(h2, n_rows, n_wgs, A.ctypes.data, W.ctypes.data, b.ctypes.data, out.ctypes.data, touched.ctypes.data, mode, info)
+    return rc, touched, {"n_jobs": int(info[0]), "supported": bool(info[1]), "ksplit": int(info[2]), "heaviest": info[3], "mean": info[4]}
+
+
+@pytest.mark.parametrize("n_wgs", [0, 6, 512])
+@pytest.mark.parametrize("kind,p,n_rows,ksplit", [
+    ("deconv_fwd", (4, 4, 7, 7, 256, 128, 128), 37, 4),        # Generator.2 forward: 9 taps x 8 chunks = 72; ragged last row block
+    ("deconv_fwd", (7, 7, 14, 14, 128, 64, 64), 64, 2),        # Generator.3 forward: 9 x 4 = 36 chunks
+    ("deconv_fwd", (8, 8, 16, 16, 128, 64, 64), 5, 2),         # CelebA's: fewer rows than one row block
+    ("deconv_bwd", (7, 7, 14, 14, 128, 64, 128), 33, 2),       # backward of Generator.3: 25 x 2 = 50 chunks, but K extent 64 = 8
+                                                               # k8-steps per tap caps the split at 2 (whole ring turns per wave)
+    ("deconv_bwd", (4, 4, 7, 7, 256, 128, 256), 70, 4),        # backward of Generator.2: 25 x 4 = 100 chunks
+])
+def test_fragment_order_lists_cover_every_output_once_and_match_the_oracle(lib, kind, p, n_rows, ksplit, n_wgs):
+    """dg_plan.cpp build_frag_jobs (n_wgs = 0) and build_frag_tiles (persistent waves): the records' own magic multipliers and
+    affine tap grids, executed on the host, write every used output element exactly once with the layer's value; the persistent
+    form hands every wave a contiguous range, and the heaviest wave is within one tile of the mean."""
+    rs = np.random.RandomState(11)
+    h1, h2, info, b = batched(lib, kind, *p)
+    if kind == "deconv_fwd":
+        h_in, pitch_in, e, pitch_out, cin, cout, _ = p
+        x = rs.randn(n_rows, pitch_in, pitch_in, cin); F = rs.randn(5, 5, cout, cin); bias = rs.randn(cout)
+        out = np.full((n_rows, pitch_out, pitch_out, cout), 777.0)
+        rc, touched, fi = apply_frag(lib, h2, n_rows, n_wgs, x, F, bias, out, 2)
+        assert fi["supported"] and rc == fi["n_jobs"] > 0
+        want = np.maximum(O.deconv2d(x[:, :h_in, :h_in], F, bias, e), 0)
+        np.testing.assert_allclose(out[:, :e, :e], want, rtol=1e-12, atol=1e-12)
+        assert (touched[:, :e, :e] == 1).all() and touched.sum() == n_rows * e * e * cout
+    else:
+        h_in, pitch_out, e, a_pitch, cin, cout, _ = p
+        dy = rs.randn(n_rows, a_pitch, a_pitch, cout); F = rs.randn(5, 5, cout, cin)
+        Ft = np.ascontiguousarray(F.transpose(0, 1, 3, 2))
+        hact = rs.randn(n_rows, pitch_out, pitch_out, cin)
+        out = hact.copy()
+        rc, touched, fi = apply_frag(lib, h2, n_rows, n_wgs, dy, Ft, None, out, 3)
+        assert fi["supported"] and rc == fi["n_jobs"] > 0
+        want = O.deconv2d_backward_input(dy[:, :e, :e], F, h_in) * (hact[:, :h_in, :h_in] > 0)
+        np.testing.assert_allclose(out[:, :h_in, :h_in], want, rtol=1e-12, atol=1e-12)
+        assert (touched[:, :h_in, :h_in] == 1).all() and touched.sum() == n_rows * h_in * h_in * cin
+    if n_wgs == 0:
+        assert fi["ksplit"] == ksplit
+    else:
+        assert fi["ksplit"] == 1                                   # a persistent wave owns its tile's whole K axis
+        biggest = max(k for _, k in b["classes"]) + 1.5
+        assert fi["heaviest"] <= fi["mean"] + biggest + 1e-9
+    lib.dgp2_free(h2); lib.dgp_free(h1)
+
+
+def test_fragment_order_path_refuses_layers_it_cannot_address(lib):
+    """K extent 32 (not 64 / 128 / 256) -> frag_supported is false and the engine keeps dg_gemm.hip (dg_engine.cpp frag_shapes_ok)."""
+    h1, h2, info, b = batched(lib, "deconv_fwd", 4, 4, 7, 7, 32, 64, 64)
+    out = np.zeros((4, 7, 7, 64))
+    rc, touched, fi = apply_frag(lib, h2, 4, 0, np.zeros((4, 4, 4, 32)), np.zeros((5, 5, 64, 32)), np.zeros(64), out, 2)
+    assert rc == 0 and not fi["supported"] and touched.sum() == 0
+    lib.dgp2_free(h2); lib.dgp_free(h1)
