@@ -156,7 +156,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(float* __restrict__ a
     const float4 be = *reinterpret_cast<const float4*>(offset + c);
     float4 xh, o;
     xh.x = (v.x - mu.x) * rs.x; xh.y = (v.y - mu.y) * rs.y; xh.z = (v.z - mu.z) * rs.z; xh.w = (v.w - mu.w) * rs.w;
-    o.x = xh.x * g.x + be.x; o.y = xh.y * g.y + be.y; o.z = xh.z * g.z + be.z; o.w = xh.w * g.w + be.w;
+    // (explicit fma: EPI_MASK_STATS and the Batchnorm form of the MNIST tail re-form the ReLU gate from `pre` with this expression)
+    o.x = __builtin_fmaf(xh.x, g.x, be.x); o.y = __builtin_fmaf(xh.y, g.y, be.y); o.z = __builtin_fmaf(xh.z, g.z, be.z); o.w = __builtin_fmaf(xh.w, g.w, be.w);
     if (relu) {
         o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
     }
@@ -245,16 +246,31 @@ __global__ __launch_bounds__(256) void bn_fold_blocks_kernel(const float* __rest
     }
 }
 
-void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift) {
+// block sums -> at most BN_FOLD_RANGES float64 partials in a.part; returns the number of ranges
+static int fold_blocks(const BnArgs& a, const float* block_sums, int nblk, hipStream_t s) {
     const int per_range = (nblk + BN_FOLD_RANGES - 1) / BN_FOLD_RANGES;
     const int ranges = (nblk + per_range - 1) / per_range;
     const int quads = (2 * a.C) / 4;
     hipLaunchKernelGGL(bn_fold_blocks_kernel, dim3((unsigned)ranges, (unsigned)((quads + 255) / 256)), dim3(256), 0, s, block_sums, a.part, nblk, a.C, per_range);
+    return ranges;
+}
+
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift) {
+    const int ranges = fold_blocks(a, block_sums, nblk, s);
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1,
                        shift);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);
+}
+
+void launch_bn_backward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, hipStream_t s) {
+    const int ranges = fold_blocks(a, block_sums, nblk, s);
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.bstats, 0,
+                       (const float*)nullptr);
+    const long long total = (long long)a.rows * a.C;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
+                       a.bstats, a.scale, total, a.C);
 }
 
 void launch_bn_backward(const BnArgs& a, hipStream_t s) {

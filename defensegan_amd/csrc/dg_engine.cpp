@@ -92,6 +92,10 @@ int build_plans(dg_handle* h) {
             GemmOp& op = h->Bd[d];
             op.name = std::string("B") + s.name[10];
             op.mode = dg::EPI_MASK;      // every backward output lands on a ReLU activation (h1, h2, h3)
+            // behind a Batchnorm over (rows x positions) the epilogue also leaves that layer's backward sums (BN1 normalises
+            // every (position, channel) feature by itself -- its columns are not the GEMM's: separate pass)
+            op.bn_act = -1;
+            if (in.has_bn && in.bn_rows > 1 && h->bn_fused >= 2) { op.mode = dg::EPI_MASK_STATS; op.bn_act = d; }
             // the incoming gradient is non-zero on the whole stored map after a BN backward, else only on the used block
             dg::LayerPlan base = dg::plan_deconv_bwd(in.valid, in.pitch, out.has_bn ? out.pitch : out.valid, out.pitch, s.cin,
                                                      s.cout, s.cin);
@@ -163,7 +167,11 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
                 // 32-row statistics blocks of the producing GEMM at `cap` rows (dg_plan.h stat_blocks: ceil(rows * positions / 32)
                 // per tap class); bn_forward refuses a launch that would need more
                 const GemmOp& producer = d == 0 ? h->F1 : h->Fd[(size_t)d - 1];
-                const size_t blocks = (size_t)dg::stat_blocks(producer.bplan, (int)std::min<int64_t>(cap, 1 << 24));
+                size_t blocks = (size_t)dg::stat_blocks(producer.bplan, (int)std::min<int64_t>(cap, 1 << 24));
+                // (the backward GEMM that writes this activation's gradient leaves ITS block sums in the same buffer: the forward
+                // sums are consumed right behind the forward GEMM)
+                if (d + 1 < nd && h->Bd[(size_t)d].mode == dg::EPI_MASK_STATS)
+                    blocks = std::max(blocks, (size_t)dg::stat_blocks(h->Bd[(size_t)d].bplan, (int)std::min<int64_t>(cap, 1 << 24)));
                 HIP_TRY(hipMalloc(&a.block_sums, blocks * 2 * (size_t)a.bn_C * sizeof(float)));
                 a.block_cap = (int64_t)blocks;
             }
@@ -173,7 +181,10 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
     }
     if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
     h->F1.stats = h->ai[0].block_sums; h->F1.stats_cap = h->ai[0].block_cap;
-    for (int d = 0; d + 1 < nd; ++d) { h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums; h->Fd[(size_t)d].stats_cap = h->ai[d + 1].block_cap; }
+    for (int d = 0; d + 1 < nd; ++d) {
+        h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums; h->Fd[(size_t)d].stats_cap = h->ai[d + 1].block_cap;
+        h->Bd[(size_t)d].stats = h->ai[d].block_sums; h->Bd[(size_t)d].stats_cap = h->ai[d].block_cap;
+    }
     h->cap_rows = cap;
     return DG_OK;
 }
@@ -332,7 +343,7 @@ int run_gemm(dg_handle* h, GemmOp& op, const float* A, float* Out, int n_rows, h
     if (lin_stationary(h, op)) return run_lin_stationary(h, op, A, Out, n_rows, s, prof);
     const JobList* jl = find_jobs(op, n_rows);
     if (!jl) return fail(DG_E_STATE, "layer %s has no job list for %d rows (prepare_rows was skipped)", op.name.c_str(), n_rows);
-    if (op.mode == dg::EPI_BIAS_STATS && (!op.stats || dg::stat_blocks(op.bplan, n_rows) > op.stats_cap))
+    if ((op.mode == dg::EPI_BIAS_STATS || op.mode == dg::EPI_MASK_STATS) && (!op.stats || dg::stat_blocks(op.bplan, n_rows) > op.stats_cap))
         return fail(DG_E_STATE, "layer %s: %lld statistics blocks at %d rows, the buffer holds %lld", op.name.c_str(),
                     (long long)dg::stat_blocks(op.bplan, n_rows), n_rows, (long long)op.stats_cap);
     int group = 0;                                   // the row group launching: its own copy of the list's pair scratch
@@ -585,19 +596,22 @@ bool update_folds(const dg_handle* h) {
 int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* uf = nullptr) {
     const int nd = (int)h->dec.size();
     const int64_t r0 = g.row0;
+    // Batchnorm backward of activation k: the sums come from the epilogue of the GEMM that wrote dy (EPI_MASK_STATS) or from a pass
+    auto bn_backward = [&](int k) {
+        ProfScope ps(h, g.s, prof, "BNb", 0.0);
+        const GemmOp* producer = k + 1 < nd ? &h->Bd[(size_t)k] : nullptr;
+        if (producer && producer->mode == dg::EPI_MASK_STATS)
+            dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->ai[k].block_sums, (int)dg::stat_blocks(producer->bplan, g.n_rows), g.s);
+        else
+            dg::launch_bn_backward(bn_args(h, h->ai[k], g.n_rows), g.s);
+    };
     for (int d = nd - 2; d >= 0; --d) {
-        if (h->ai[d + 1].has_bn) {
-            ProfScope ps(h, g.s, prof, "BNb", 0.0);
-            dg::launch_bn_backward(bn_args(h, h->ai[d + 1], g.n_rows), g.s);
-        }
+        if (h->ai[d + 1].has_bn) bn_backward(d + 1);
         int rc = run_gemm(h, h->Bd[d], h->act[d + 1] + r0 * h->act_row[d + 1], h->act[d] + r0 * h->act_row[d], g.n_rows, g.s, prof,
                           frag_on(h) && r0 == 0 ? h->gate[d] : nullptr);
         if (rc) return rc;
     }
-    if (h->ai[0].has_bn) {
-        ProfScope ps(h, g.s, prof, "BNb", 0.0);
-        dg::launch_bn_backward(bn_args(h, h->ai[0], g.n_rows), g.s);
-    }
+    if (h->ai[0].has_bn) bn_backward(0);
     if (uf) return run_lin_stationary(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof, uf);
     return run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
 }
@@ -618,6 +632,8 @@ int rebuild_plans(dg_handle* h) {
         h->Fd[d].stats = h->ai[d + 1].block_sums;
         h->Fd[d].stats_cap = h->ai[d + 1].block_cap;
         h->Bd[d].W = h->Ft[d];
+        h->Bd[d].stats = h->ai[d].block_sums;
+        h->Bd[d].stats_cap = h->ai[d].block_cap;
     }
     return DG_OK;
 }

@@ -103,8 +103,9 @@ struct GemmOp {
     int mode = 0;
     const float* W = nullptr;
     const float* bias = nullptr;
-    float* stats = nullptr;   // EPI_BIAS_STATS: the block sums of the activation this layer produces (ActInfo::block_sums)
+    float* stats = nullptr;   // EPI_BIAS_STATS / EPI_MASK_STATS: the block sums of the activation this layer writes (ActInfo::block_sums)
     int64_t stats_cap = 0;    // blocks that buffer holds
+    int bn_act = -1;          // EPI_MASK_STATS: index (dg_handle::ai) of the activation whose ReLU gradient this layer writes
 };
 
 constexpr int kJobTraceCap = 65536;
@@ -181,7 +182,7 @@ struct dg_handle {
                                    // slower on every layer (profiles/r05_ab_list_orders.txt): off
     // Batchnorm forward statistics from the producing GEMM's epilogue (per-32-row-block column sums, EPI_BIAS_STATS) instead of a
     // pass over the pre-activations; 0 = the separate pass (cross-check)
-    int bn_fused = 1;
+    int bn_fused = 2;         // option "bn_fused": 0 = separate statistics passes, 1 = forward sums from the GEMM epilogue, 2 = backward sums too
     // The kernel has two instantiations per (family, epilogue, level): with and without the K-pair hand-off code.  A list without
     // pairs needs neither, and hipcc allocates and schedules their main loops differently: measured on MNIST at 2560 rows the PAIR
     // form is 0.7 % FASTER on Generator.3's backward and 0.6 % on Generator.2's forward, 0.3 % slower on Generator.3's forward

@@ -73,6 +73,11 @@ dg::GemmArgs gemm_args(dg_handle* h, const GemmOp& op, const JobList& jl, const 
     a.stats_cols = op.bplan.ncols;
     a.gate_bits = nullptr;
     a.gate_words = 0;
+    a.bn_pre = a.bn_fstats = a.bn_scale = a.bn_offset = nullptr;
+    if (op.bn_act >= 0) {
+        const ActInfo& bn = h->ai[(size_t)op.bn_act];
+        a.bn_pre = bn.xhat; a.bn_fstats = bn.fstats; a.bn_scale = bn.scale; a.bn_offset = bn.offset;
+    }
     a.n_jobs = jl.n_jobs;
     a.min_level = jl.min_level;
 #ifdef DG_MEASURE

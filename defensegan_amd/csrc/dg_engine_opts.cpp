@@ -83,10 +83,11 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         h->update_fold = atoi(value) != 0;
         return DG_OK;
     }
-    if (k == "bn_fused") {               // 1 = Batchnorm forward statistics from the GEMM epilogue (default), 0 = a separate pass
+    if (k == "bn_fused") {               // Batchnorm sums from the producing GEMM's epilogue: 2 = forward and backward (default), 1 = forward, 0 = passes
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
-        h->bn_fused = atoi(value) != 0;
+        h->bn_fused = atoi(value) < 0 ? 0 : (atoi(value) > 2 ? 2 : atoi(value));
+        free_workspace(h);               // the block-sum buffers exist (and are sized) by it
         drop_job_lists(h);
         return rebuild_plans(h);
     }

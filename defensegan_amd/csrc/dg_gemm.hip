@@ -177,6 +177,9 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
 
     // ReluGrad epilogue: the activation values that gate the result are fetched during the LAST K chunk.
     f32x4 oldv[TM][TN][4];
+    // EPI_MASK: the activation the gradient overwrites; EPI_MASK_STATS: the pre-activations of the Batchnorm layer in front of it
+    const float* gate_src = out_base;
+    if constexpr (MODE == EPI_MASK_STATS) gate_src = g.bn_pre + (long long)jb.n_first * g.out_rowstride + jb.n0;
     auto prefetch_mask = [&]() {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -186,7 +189,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ovalid[i][p]) v = *reinterpret_cast<const f32x4*>(out_base + orow[i][p] + col);
+                    if (ovalid[i][p]) v = *reinterpret_cast<const f32x4*>(gate_src + orow[i][p] + col);
                     oldv[i][j][p] = v;
                 }
         }
@@ -209,7 +212,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         }
     };
     if (MODE == EPI_MASK_BITS && nchunks == 0) prefetch_gates();
-    if (MODE == EPI_MASK && nchunks == 0) {
+    if ((MODE == EPI_MASK || MODE == EPI_MASK_STATS) && nchunks == 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -265,7 +268,7 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][e], b[cur][j][e], acc[i][j], 0, 0, 0);
                 if constexpr (!LAST) {
                     if (e < slots_here) issue_slot(first + e, nx);        // slot first+e rides behind MFMA group e
-                } else if constexpr (MODE == EPI_MASK) {
+                } else if constexpr (MODE == EPI_MASK || MODE == EPI_MASK_STATS) {
                     if (kk == 0 && e == 0) prefetch_mask();
                 } else if constexpr (MODE == EPI_MASK_BITS) {
                     if (kk == 0 && e == 0) prefetch_gates();
@@ -356,6 +359,13 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
         const int col = wn * (BN / WN) + j * 32 + ec;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if constexpr (MODE == EPI_BIAS || MODE == EPI_BIAS_RELU || MODE == EPI_BIAS_STATS) bv = *reinterpret_cast<const f32x4*>(g.bias + jb.n0 + col);
+        f32x4 bn_mu = bv, bn_rs = bv, bn_g = bv, bn_be = bv;           // EPI_MASK_STATS: the Batchnorm constants of this lane's 4 columns
+        if constexpr (MODE == EPI_MASK_STATS) {
+            bn_mu = *reinterpret_cast<const f32x4*>(g.bn_fstats + jb.n0 + col);
+            bn_rs = *reinterpret_cast<const f32x4*>(g.bn_fstats + g.stats_cols + jb.n0 + col);
+            bn_g = *reinterpret_cast<const f32x4*>(g.bn_scale + jb.n0 + col);
+            bn_be = *reinterpret_cast<const f32x4*>(g.bn_offset + jb.n0 + col);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};     // EPI_BIAS_STATS: this lane's rows of the 32-row block
@@ -376,11 +386,17 @@ __device__ __forceinline__ void run_job(const GemmArgs& g, const JobDesc jb, cha
                     if constexpr (MODE == EPI_BIAS_RELU) t = t > 0.f ? t : 0.f;
                     if constexpr (MODE == EPI_MASK) t = oldv[i][j][p][q] > 0.f ? t : 0.f;
                     if constexpr (MODE == EPI_MASK_BITS) t = ((gatew[i][j][p] >> (ec + q)) & 1u) ? t : 0.f;
+                    if constexpr (MODE == EPI_MASK_STATS) {
+                        // xhat and relu(bn(pre)) > 0 by the float expressions of bn_apply_fwd_kernel / bn_apply_bwd_kernel (dg_bn.hip)
+                        const float xh = (oldv[i][j][p][q] - bn_mu[q]) * bn_rs[q];
+                        t = __builtin_fmaf(xh, bn_g[q], bn_be[q]) > 0.f ? t : 0.f;
+                        if (ovalid[i][p]) { s1[q] += t; s2[q] = __builtin_fmaf(t, xh, s2[q]); }
+                    }
                     v[q] = t;
                 }
                 if (ovalid[i][p]) *reinterpret_cast<f32x4*>(out_base + orow[i][p] + col) = v;
             }
-            if constexpr (MODE == EPI_BIAS_STATS) {
+            if constexpr (MODE == EPI_BIAS_STATS || MODE == EPI_MASK_STATS) {
                 // the 8 lanes that share this lane's 4 columns hold the other rows of the 32-row block (er = lane >> 3): a fixed
                 // xor tree over lane bits 3..5, the same for every job shape -- a block's sums do not depend on the job list
 #pragma unroll
@@ -468,6 +484,7 @@ void launch_f(const GemmArgs& a, hipStream_t s) {
         case EPI_BIAS_RELU: launch_fm<FAM, EPI_BIAS_RELU>(a, s); break;
         case EPI_BIAS_STATS: launch_fm<FAM, EPI_BIAS_STATS>(a, s); break;
         case EPI_MASK_BITS: launch_fm<FAM, EPI_MASK_BITS>(a, s); break;
+        case EPI_MASK_STATS: launch_fm<FAM, EPI_MASK_STATS>(a, s); break;
         default: launch_fm<FAM, EPI_MASK>(a, s); break;
     }
 }

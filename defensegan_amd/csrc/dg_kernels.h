@@ -43,6 +43,10 @@ enum EpiMode : int {
                          // (GemmArgs::stats): the Batchnorm forward statistics without a pass over the pre-activations
     EPI_MASK_BITS = 5,   // out = gate bit ? acc : 0: ReluGrad with the gates as one bit per element (GemmArgs::gate_bits) -- the
                          // fragment-order path, whose forward activations do not live in the buffer the gradient is written to
+    EPI_MASK_STATS = 6,  // ReluGrad behind a Batchnorm layer, with that layer's BACKWARD sums: the gate is re-formed from the layer's
+                         // pre-activations (GemmArgs::bn_pre; relu(bn(pre)) > 0 by the float expression bn_apply_fwd_kernel stored), and
+                         // per 32-row block the column sums of dy and dy * xhat go to GemmArgs::stats -- the statistics pass of
+                         // launch_bn_backward (a read of dy and of the pre-activations) is not run (launch_bn_backward_from_blocks)
 };
 
 // ---- position-batched gathered implicit GEMM (dg_gemm.hip) --------------------------------------
@@ -80,6 +84,12 @@ struct GemmArgs {
     // EPI_MASK_BITS: [rows][gate_words] words, bit f % 32 of word f / 32 = (activation f of the row > 0); gate_words = out_rowstride / 32
     const unsigned* gate_bits;
     int gate_words;
+    // EPI_MASK_STATS: the Batchnorm layer in front of the ReLU whose gradient this launch writes -- its pre-activations (geometry of
+    // Out), forward statistics [2][stats_cols] (mean, rstd), scale and offset [stats_cols]
+    const float* bn_pre;
+    const float* bn_fstats;
+    const float* bn_scale;
+    const float* bn_offset;
 #ifdef DG_MEASURE
     long long* trace;        // optional [n_jobs][4] per-workgroup {start, end (100 MHz ticks), HW_ID, chunks}
 #endif
@@ -254,5 +264,8 @@ void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
 // carry no bias-sized offset
 void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift);
 void launch_bn_backward(const BnArgs& a, hipStream_t s);
+// the backward pass when the producer of dy (a GEMM epilogue in EPI_MASK_STATS, or the MNIST tail in its Batchnorm form) has left
+// per-block column sums of dy and dy * xhat in `block_sums` [nblk][2][C] (float): fold + finalize (float64) + apply
+void launch_bn_backward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, hipStream_t s);
 
 }  // namespace dg

@@ -174,8 +174,10 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      again with them, 2 always.  Measured: the launches last the same (profiles/r05_ab_prio.txt)
  *   "jobs.spread"      1: the first dispatch round of a multi-round list mixes all job lengths (dg_plan.h spread_order).  Default 0:
  *                      slower on every layer (profiles/r05_ab_list_orders.txt)
- *   "bn_fused"         1 (default): with use_bn the Batchnorm forward statistics are per-32-row-block column sums taken in the producing
- *                      GEMM's epilogue; 0: a separate pass over the pre-activations (float64 sums from the first add)
+ *   "bn_fused"         with use_bn, where the Batchnorm sums come from.  1: the forward statistics are per-32-row-block column sums taken
+ *                      in the producing GEMM's epilogue; 2 (default): so are the backward sums (of dy and dy * xhat) of the layers
+ *                      normalised over rows x positions, taken in the epilogue of the GEMM that writes dy (which re-forms the ReLU gate
+ *                      and xhat from the layer's pre-activations); 0: separate passes (float64 sums from the first add)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
  *   "lr_schedule"      "constant" (default): lr == rec_lr at every step, which is what the reference executes -- the step variable
  *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,

@@ -152,6 +152,13 @@ def test_bn_statistics_from_the_gemm_epilogue(arch, B, R):
     np.testing.assert_allclose(l1, l0, rtol=1e-5)
     err = np.abs(d1 - d0).max(axis=1) / np.abs(d0).max()
     assert np.median(err) < 1e-5 and (err < 1e-4).mean() >= 0.95, np.sort(err)[-3:]       # (a ReLU gate at rounding distance may move a row)
+    # round 6: the default (bn_fused = 2) also takes the BACKWARD sums (dy, dy * xhat) of the layers normalised over rows x positions
+    # in the epilogue of the GEMM that writes dy (EPI_MASK_STATS; the gate is re-formed from the pre-activations).  Against
+    # bn_fused = 1 (backward sums by a float64 pass): the same forward bits, the gradient to the rounding of 32-row float32 sums
+    yf, lf, df = run({"bn_fused": 1})
+    assert np.array_equal(yf, y1) and np.array_equal(lf, l1)
+    errf = np.abs(d1 - df).max(axis=1) / np.abs(df).max()
+    assert np.median(errf) < 1e-5 and errf.max() < 1e-4, np.sort(errf)[-3:]
     for opts in ({"jobs.min_level": 1, "jobs.tune": 0}, {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.slack": 0.01, "jobs.min_level": 0}):
         y2, l2, d2 = run(opts)
         assert np.array_equal(y2, y1) and np.array_equal(l2, l1) and np.array_equal(d2, d1), opts
