@@ -165,12 +165,13 @@ def socket0_core_cpus():
         return []
 
 
-def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
+def cpu_baseline(arch, params, x_np, R, L, budget_s=16.0):
     """The oracle's torch-CPU formulation (a PORT of the reference graph: TF 1.7 cannot be installed here) on this box's host
     cores, by a FIXED rule (CPU_BASELINE_THREADS): 16 threads pinned to 16 distinct physical cores of socket 0, one warm-up of two
-    steps, then TWO batches of 16 images over the FULL L steps -- measured, not a short sample scaled by (2L-1); `value` is the
-    faster one, `spread` = (slower - faster) / faster, both times are in `sample`.  If the warm-up predicts more than `budget_s`
-    seconds per batch the batch shrinks to 8 / 4 images before the step count does."""
+    steps, then TWO batches over the FULL L steps -- measured, not a short sample scaled by (2L-1); `value` is the faster one,
+    `spread` = (slower - faster) / faster, both times are in `sample`.  A batch is 64 images, halved (32 / 16 / 8 / 4) while a warm
+    two-step run predicts more than `budget_s` seconds for it (MNIST: 64 images, ~10 s; CelebA: 16 images, ~16 s), and only then
+    are the steps cut: 20-30 s of CPU work in all."""
     from oracle import torch_ref as T          # checker / baseline only -- never on the product path
     phys, ncpu = physical_cores_one_socket()
     threads = max(1, min(CPU_BASELINE_THREADS, phys or ncpu, ncpu))
@@ -190,10 +191,10 @@ def cpu_baseline(arch, params, x_np, R, L, budget_s=40.0):
     torch.set_num_threads(threads)
     gen = T.TorchGenerator(params, arch)
     a = archs.make_arch(arch)
-    nimg = min(16, len(x_np))
+    nimg = min(64, len(x_np))
     z0 = synth.make_z(nimg * R, a.latent_dim, seed=3)
     try:
-        T.reconstruct(params, x_np[:nimg], z0, R, 1, arch=arch, gen=gen)      # warm-up (thread pool, allocator)
+        T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)      # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
         T.reconstruct(params, x_np[:nimg], z0, R, 2, arch=arch, gen=gen)
         per_pass = (time.perf_counter() - t0) / 3.0                            # L steps = 2L - 1 passes over nimg images
