@@ -259,6 +259,7 @@ void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int
     const int ranges = fold_blocks(a, block_sums, nblk, s);
     hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1,
                        shift);
+    if (relu < 0) return;              // statistics only: the consumer applies relu(bn(.)) itself (the MNIST tail's Batchnorm form)
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.scale, a.offset, total, a.C, relu);

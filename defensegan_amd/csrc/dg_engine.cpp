@@ -117,6 +117,7 @@ void free_workspace(dg_handle* h) {
     for (auto& g : h->gate) if (g) { (void)hipFree(g); g = nullptr; }
     for (auto& a : h->ai) { a.buf = nullptr; fr(a.xhat); fr(a.block_sums); a.block_cap = 0; }
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
+    fr(h->tail_bn_sums); h->tail_bn_sums_wgs = 0;
     if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
     h->cap_rows = 0;
 }
@@ -180,6 +181,11 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         }
     }
     if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
+    // Batchnorm form of the MNIST tail: 10 records [2][C] per workgroup (dg_tail_mnist.hip mnist_tail_pipe3_kernel<C, true>)
+    if (h->arch == DG_ARCH_MNIST28 && h->ai[(size_t)nd - 1].has_bn && h->bn_fused >= 2 && h->tail_pipe > 0) {
+        HIP_TRY(hipMalloc(&h->tail_bn_sums, (size_t)h->tail_pipe * 10 * 2 * (size_t)h->ai[(size_t)nd - 1].bn_C * sizeof(float)));
+        h->tail_bn_sums_wgs = h->tail_pipe;
+    }
     h->F1.stats = h->ai[0].block_sums; h->F1.stats_cap = h->ai[0].block_cap;
     for (int d = 0; d + 1 < nd; ++d) {
         h->Fd[(size_t)d].stats = h->ai[d + 1].block_sums; h->Fd[(size_t)d].stats_cap = h->ai[d + 1].block_cap;
@@ -485,16 +491,33 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     int rc = frag ? run_lin_stationary(h, h->F1, h->z, h->act[0], n_rows, s, prof, nullptr, h->actf[0], h->gate[0])
                   : run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
     if (rc) return rc;
+    const int nd = (int)h->dec.size();
+    // The MNIST tail in its Batchnorm form (this launch runs mnist_tail_pipe3_kernel and the last GEMM is behind a Batchnorm whose sums
+    // come from epilogues): the tail applies relu(bn(.)) to the pre-activations itself and leaves that layer's backward sums
+    dg::MnistTailArgs t;
+    bool tail_bn = false;
+    if (h->arch == DG_ARCH_MNIST28) {
+        t.n_rows = n_rows;
+        t.C = h->dec[(size_t)nd - 1].cin;
+        t.do_backward = tail_backward ? 1 : 0;
+        t.pipe = h->tail_pipe;
+        // the third-generation kernel writes neither the per-row loss nor y: a launch whose loss or image is read (dg_loss_grad
+        // with out_loss and / or out_y) runs the first
+        t.pipe_version = (h->tail_pipe_version == 3 && (want_loss || want_y)) ? 1 : h->tail_pipe_version;
+        const ActInfo& la = h->ai[(size_t)nd - 1];
+        tail_bn = la.has_bn && h->bn_fused >= 2 && h->Fd[(size_t)nd - 2].mode == dg::EPI_BIAS_STATS && dg::mnist_tail_runs_pipe3(t) &&
+                  h->tail_bn_sums && h->tail_bn_sums_wgs == t.pipe && r0 == 0;
+    }
+    h->tail_left_bn_sums = tail_bn;
     auto bn_forward = [&](int d, const GemmOp& producer) {
         ProfScope ps(h, s, prof, "BNf", 0.0);
         if (producer.mode == dg::EPI_BIAS_STATS)
-            dg::launch_bn_forward_from_blocks(bn_args(h, h->ai[d], n_rows), h->ai[d].block_sums, (int)dg::stat_blocks(producer.bplan, n_rows), 1, s,
-                                              producer.bias);
+            dg::launch_bn_forward_from_blocks(bn_args(h, h->ai[d], n_rows), h->ai[d].block_sums, (int)dg::stat_blocks(producer.bplan, n_rows),
+                                              (tail_bn && d == nd - 1) ? -1 : 1, s, producer.bias);
         else
             dg::launch_bn_forward(bn_args(h, h->ai[d], n_rows), 1, s);
     };
     if (h->ai[0].has_bn) bn_forward(0, h->F1);
-    const int nd = (int)h->dec.size();
     for (int d = 0; d + 1 < nd; ++d) {
         if (frag) {
             // the last of these layers feeds the tail, which reads NHWC; the others feed the next fragment-order layer
@@ -510,22 +533,21 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     }
     const DeconvSpec& last = h->dec[nd - 1];
     if (h->arch == DG_ARCH_MNIST28) {
-        dg::MnistTailArgs t;
         t.h3 = h->act[nd - 1] + r0 * h->act_row[nd - 1];
         t.F5 = h->F[nd - 1];
         t.b5 = h->bias[nd - 1];
         t.x = x + (r0 / R) * h->P;
         t.loss = h->loss + r0;
         t.y = want_y ? h->y + r0 * h->P : nullptr;
-        t.n_rows = n_rows;
         t.R = R;
-        t.C = last.cin;
-        t.do_backward = tail_backward ? 1 : 0;
-        t.pipe = h->tail_pipe;
         t.want_loss = want_loss ? 1 : 0;
-        // the third-generation kernel writes neither the per-row loss nor y: a launch whose loss or image is read (dg_loss_grad
-        // with out_loss and / or out_y) runs the first
-        t.pipe_version = (h->tail_pipe_version == 3 && (want_loss || want_y)) ? 1 : h->tail_pipe_version;
+        t.bn_pre = t.bn_fstats = t.bn_scale = t.bn_offset = nullptr;
+        t.bn_sums = nullptr;
+        if (tail_bn) {
+            const ActInfo& la = h->ai[(size_t)nd - 1];
+            t.bn_pre = la.xhat; t.bn_fstats = la.fstats; t.bn_scale = la.scale; t.bn_offset = la.offset;
+            t.bn_sums = h->tail_bn_sums;
+        }
 #ifdef DG_MEASURE
         t.dbg = h->tail_dbg;
         t.trace = h->d_tail_trace;
@@ -600,7 +622,9 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* u
     auto bn_backward = [&](int k) {
         ProfScope ps(h, g.s, prof, "BNb", 0.0);
         const GemmOp* producer = k + 1 < nd ? &h->Bd[(size_t)k] : nullptr;
-        if (producer && producer->mode == dg::EPI_MASK_STATS)
+        if (!producer && h->tail_left_bn_sums)         // the tail wrote dy and its sums (run_forward of this step)
+            dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->tail_bn_sums, h->tail_bn_sums_wgs * 10, g.s);
+        else if (producer && producer->mode == dg::EPI_MASK_STATS)
             dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->ai[k].block_sums, (int)dg::stat_blocks(producer->bplan, g.n_rows), g.s);
         else
             dg::launch_bn_backward(bn_args(h, h->ai[k], g.n_rows), g.s);

@@ -118,6 +118,11 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         return DG_OK;
     }
     if (k == "tail_pipe") {
+        if (h->use_bn) {                 // the Batchnorm form of the tail leaves one set of records per workgroup (ensure_workspace)
+            HIP_TRY(hipSetDevice(h->device));
+            HIP_TRY(hipDeviceSynchronize());
+            free_workspace(h);
+        }
         h->tail_pipe = atoi(value);
         return DG_OK;
     }

@@ -189,6 +189,16 @@ struct MnistTailArgs {
     int pipe;            // > 0: persistent pipelined kernel with this many workgroups when n_rows >= 2 * pipe (C = 64)
     int want_loss;       // 0: nobody reads this launch's per-row loss (every launch of a projection but the last forward): the third-
                          // generation pipelined kernel, which does not reduce it, may run
+    // Batchnorm form of the third-generation pipelined kernel (mnist_tail_pipe3_kernel<C, true>; nullptr = plain): the input map is
+    // bn_pre, the PRE-ACTIVATIONS of Generator.3's Batchnorm layer (h3 is then written only: da3), with that layer's forward statistics
+    // [2][C] (mean, rstd), scale and offset [C]; bn_sums receives [pipe * 10][2][C] backward sums (dy, dy * xhat) for
+    // launch_bn_backward_from_blocks.  Other kernels of this launcher ignore the fields: callers set them only when that kernel runs
+    // (mnist_tail_runs_pipe3)
+    const float* bn_pre;
+    const float* bn_fstats;
+    const float* bn_scale;
+    const float* bn_offset;
+    float* bn_sums;
     int pipe_version;    // 3: mnist_tail_pipe3_kernel (one GEMM per wave, 16 waves; no loss); 2: mnist_tail_pipe2_kernel (matrix work levelled over the SIMDs, positions 192..195 on the gather waves); 1: mnist_tail_pipe_kernel
 #ifdef DG_MEASURE
     int dbg;             // timing experiments only: 1 skip gather, 2 skip forward GEMM, 3 skip backward GEMM
@@ -196,6 +206,8 @@ struct MnistTailArgs {
 #endif
 };
 void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s);   // dg_tail_mnist.hip
+// does this launch run mnist_tail_pipe3_kernel (the only one with a Batchnorm form)?
+inline bool mnist_tail_runs_pipe3(const MnistTailArgs& a) { return a.pipe > 0 && a.do_backward && a.C == 64 && a.n_rows >= 2 * a.pipe && a.pipe_version == 3; }
 
 // ---- CelebA tail: Generator.6 (64 -> 3, 64x64) + tanh + loss + backward to da5 ----------------
 struct CelebaTailArgs {
@@ -262,6 +274,7 @@ void launch_bn_forward(const BnArgs& a, int relu, hipStream_t s);
 // finalize (float64) + apply -- no pass over the pre-activations for the statistics.  The block sums are those of (pre - shift[c]):
 // the producing GEMM takes them before it adds its bias (shift = that bias, per column), so that the float32 sums of x and x^2
 // carry no bias-sized offset
+// relu < 0: statistics only (a.fstats), nothing is applied -- the consumer of the layer does that itself
 void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift);
 void launch_bn_backward(const BnArgs& a, hipStream_t s);
 // the backward pass when the producer of dy (a GEMM epilogue in EPI_MASK_STATS, or the MNIST tail in its Batchnorm form) has left

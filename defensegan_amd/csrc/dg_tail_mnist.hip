@@ -717,12 +717,21 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe2_kernel(MnistTailArgs a) 
 //   1 KB image one of them stages by LDS-DMA two rows ahead
 // so every SIMD carries 84-90 MFMAs per step (5.8 k cycles) and no MFMA is spent on padding rows.  Same barrier sequence, same
 // buffers and the same arithmetic per element as mnist_tail_pipe_kernel (tests/test_gpu_variants.py: bit-identical).
-template <int C>
+// BN (round 6, MnistTailArgs::bn_pre): the input map is the PRE-ACTIVATIONS of Generator.3's Batchnorm layer; the forward waves apply
+// relu(bn(.)) to their fragments as they leave LDS (the float expression of bn_apply_fwd_kernel: the activation image is never written
+// or read -- one pass of 2 x 128 MB less per step at 2560 rows), and the backward waves add up that layer's backward sums (dy and
+// dy * xhat per channel, xhat re-formed from the pre-activations they fetch beside their MFMAs) over all their rows; every wave
+// leaves one [2][C] record at the end (MnistTailArgs::bn_sums: 10 per workgroup, 6 tiles + positions 192..195), folded by
+// launch_bn_backward_from_blocks -- the statistics pass of the Batchnorm backward (another 2 x 128 MB) is not run either.
+template <int C, bool BN>
 __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a) {
     static_assert(C == 64, "64 channels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PSZ = 196 * MN_NKP, GSZ = MN_GR * MN_GWP;
-    float* sP = reinterpret_cast<float*>(smem);                  // [2][196][MN_NKP]
+    // BN: [4][C] mean, rstd, scale, offset at the START of LDS -- ds_read takes a 16-bit immediate offset, and addresses beyond it
+    // cost one register each (32 of them in the forward waves' conversion: measured as 200 spilled registers)
+    float* sBN = reinterpret_cast<float*>(smem);
+    float* sP = reinterpret_cast<float*>(smem) + (BN ? 4 * C : 0);     // [2][196][MN_NKP]
     float* sg = sP + 2 * PSZ;                                    // [2][31][32]
     unsigned* xmask = reinterpret_cast<unsigned*>(sg + 2 * GSZ); // [3][6 tiles][C] ReluGrad bits by row % 3
     float* sred = reinterpret_cast<float*>(xmask + 3 * 6 * C);   // [2][4]
@@ -741,12 +750,32 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
     float* scratch = reinterpret_cast<float*>(stages + 6 * (32 * C * 4) + (has_bwd ? btile : 0) * 4096);
     float* la = reinterpret_cast<float*>(stages + 6 * (32 * C * 4) + 6 * 4096);   // [2][4 positions][C] images of positions 192..195
     unsigned* lmask = reinterpret_cast<unsigned*>(la + 2 * 4 * C);                // [3][C] ReluGrad bits of 192..195, by row % 3
+    const float* in_map = BN ? a.bn_pre : a.h3;                                   // what the forward waves stage
+    float* lh = reinterpret_cast<float*>(lmask + 3 * C);                          // BN: [2 waves][2 positions][C] relu(bn(.)) of 192..195
+    unsigned* lmaskb = reinterpret_cast<unsigned*>(lh + 2 * 2 * C);               // BN: [3][2 waves][C] ReluGrad bits, two positions per word
     const int gt = tid - 768;                                    // gather thread id (G waves)
     const int gw = wave - 12;
     const int n_my = ((int)a.n_rows - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     auto row_of = [&](int k) { return (long long)blockIdx.x + (long long)k * gridDim.x; };
 
     for (int i = tid; i < 2 * GSZ; i += 1024) sg[i] = 0.f;       // zero borders of both da5 images, written once
+    if constexpr (BN) {
+        if (tid < 2 * C) sBN[tid] = a.bn_fstats[tid];
+        else if (tid < 3 * C) sBN[tid] = a.bn_scale[tid - 2 * C];
+        else if (tid < 4 * C) sBN[tid] = a.bn_offset[tid - 3 * C];
+    }
+    // relu(bn(v)) for 4 consecutive channels from c0 (dg_bn.hip bn_apply_fwd_kernel's expression, bit for bit)
+    auto bn_relu4 = [&](f32x4 v, int c0) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(sBN + c0), rs = *reinterpret_cast<const f32x4*>(sBN + C + c0);
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(sBN + 2 * C + c0), be = *reinterpret_cast<const f32x4*>(sBN + 3 * C + c0);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = __builtin_fmaf((v[e] - mu[e]) * rs[e], gm[e], be[e]);
+            o[e] = t > 0.f ? t : 0.f;
+        }
+        return o;
+    };
     for (int i = tid; i < (C / 8) * 256; i += 1024) {
         const int e = i & 3, l = (i >> 2) & 63, kk = i >> 8;
         const int kappa = l & 31, c = kk * 8 + (l >> 5) * 4 + e;
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
     constexpr int CH = C / 4;                                    // 16-B chunks per position
     constexpr int NI = 32 * CH / 64;                             // DMA instructions per tile
     auto stage_row = [&](int k) {
-        const char* src = reinterpret_cast<const char*>(a.h3 + row_of(k) * (196 * C) + (long long)tile * 32 * C);
+        const char* src = reinterpret_cast<const char*>(in_map + row_of(k) * (196 * C) + (long long)tile * 32 * C);
 #pragma unroll
         for (int qi = 0; qi < NI; ++qi) {
             const int slot = qi * 64 + lane;
@@ -776,6 +805,15 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
         for (int kk = 0; kk < C / 8; ++kk)
             av[kk] = *reinterpret_cast<const f32x4*>(stage + frow * (C * 4) + (((kk * 2 + fh) ^ (frow & (CH - 1))) << 4));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (BN) {
+            // two k-steps at a time: left alone hipcc fetches the constants of all eight first (128 registers; the kernel has 128)
+#pragma unroll
+            for (int kk = 0; kk < C / 8; kk += 2) {
+                av[kk] = bn_relu4(av[kk], kk * 8 + fh * 4);
+                av[kk + 1] = bn_relu4(av[kk + 1], kk * 8 + 8 + fh * 4);
+                asm volatile("" : "+v"(av[kk]), "+v"(av[kk + 1]) :: "memory");      // (the results exist here, and no LDS read moves across)
+            }
+        }
     };
     auto fwd = [&](int k, const f32x4 (&av)[C / 8]) {
         unsigned* mk = xmask + ((k % 3) * 6 + tile) * C;
@@ -803,15 +841,43 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
         mk[lane] = (unsigned)word;
         tail_fwd_compute_ldsw<C>(av, tile * 32, sWf, sP + (k & 1) * PSZ, MN_NKP, lane);
     };
+    // BN: this lane's backward sums over all its rows -- after the transposition below a lane owns 4 consecutive channels (ec) of the
+    // tile's rows er, er + 8, er + 16, er + 24, for both 32-channel groups
+    f32x4 bs1[C / 32], bs2[C / 32];
+#pragma unroll
+    for (int u = 0; u < C / 32; ++u) { bs1[u] = f32x4{0.f, 0.f, 0.f, 0.f}; bs2[u] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     auto bwd = [&](int k) {
         const unsigned* mk = xmask + ((k % 3) * 6 + btile) * C;
         float* hrow = a.h3 + row_of(k) * (196 * C);
         const int qq = btile * 32 + frow;                        // tiles 0-5: every position exists
         const int oh = qq / 14, ow = qq - oh * 14;
+        // BN: the pre-activations of this lane's output elements (L2: the tile's forward wave staged them two steps ago): those of
+        // the first channel group are fetched before the MFMAs, those of the second behind them, when the operand registers are free
+        f32x4 pv[C / 32][4];
+        const float* prow = a.bn_pre + row_of(k) * (196 * C) + (long long)(btile * 32 + (lane >> 3)) * C + (lane & 7) * 4;
+        int lane_k = lane;
+        if constexpr (BN) {
+            // (the lane id as this step sees it: 13 per-lane LDS offsets of the gather are then formed here, two VALU each, instead of
+            // living in registers across the loop -- with the sums and the pre-activations the loop did not fit its 128 registers)
+            asm volatile("" : "+v"(lane_k));
+#pragma unroll
+            for (int p = 0; p < 4; ++p) pv[0][p] = *reinterpret_cast<const f32x4*>(prow + p * 8 * C);
+        }
         f32x16 acc[C / 32];
-        tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, (2 * oh) * MN_GWP + 2 * ow, true, sWb, acc, lane);
+        int gbase = (2 * oh) * MN_GWP + 2 * ow;
+        if constexpr (BN) {               // (formed from this step's lane id as well: kept across the loop it was the one spilled register,
+            const int qk = btile * 32 + (lane_k & 31), ohk = qk / 14;     // whose reload waits for vmcnt(0) = for the loads just issued)
+            gbase = (2 * ohk) * MN_GWP + 2 * (qk - ohk * 14);
+        }
+        tail_bwd_tile_ldsw<C, 1, MN_GWP>(sg + (k & 1) * GSZ, gbase, true, sWb, acc, lane_k);
         float* tb = scratch;                                     // private 4 KB: the P tile of this parity is being rewritten by the forward wave
         const int er = lane >> 3, ec = (lane & 7) * 4;
+        if constexpr (BN) {
+#pragma unroll
+            for (int u = 1; u < C / 32; ++u)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) pv[u][p] = *reinterpret_cast<const f32x4*>(prow + p * 8 * C + u * 32);
+        }
 #pragma unroll
         for (int u = 0; u < C / 32; ++u) {
             const unsigned mw = mk[u * 32 + frow];
@@ -825,6 +891,31 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
                 const int qr = btile * 32 + p * 8 + er;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(tb + (p * 8 + er) * 32 + ec);
                 *reinterpret_cast<f32x4*>(hrow + qr * C + u * 32 + ec) = v;
+                if constexpr (BN) {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(sBN + u * 32 + ec), rs = *reinterpret_cast<const f32x4*>(sBN + C + u * 32 + ec);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bs1[u][e] += v[e];
+                        bs2[u][e] = __builtin_fmaf(v[e], (pv[u][p][e] - mu[e]) * rs[e], bs2[u][e]);
+                    }
+                }
+            }
+        }
+    };
+    // one [2][C] record of a backward wave: the 8 lanes that share 4 channels hold different rows -- a fixed xor tree over lane bits 3..5
+    auto flush_bwd_sums = [&]() {
+        if constexpr (BN) {
+            float* rec = a.bn_sums + ((long long)blockIdx.x * 10 + btile) * (2 * C);
+#pragma unroll
+            for (int u = 0; u < C / 32; ++u) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 8; m < 64; m <<= 1) { bs1[u][e] += __shfl_xor(bs1[u][e], m, 64); bs2[u][e] += __shfl_xor(bs2[u][e], m, 64); }
+                if (lane < 8) {
+                    *reinterpret_cast<f32x4*>(rec + u * 32 + lane * 4) = bs1[u];
+                    *reinterpret_cast<f32x4*>(rec + C + u * 32 + lane * 4) = bs2[u];
+                }
             }
         }
     };
@@ -886,17 +977,53 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
     auto stage_left = [&](int k) {        // forward wave 5: 4 positions x C floats = 1 KB, contiguous in h3
         if (wave != 5) return;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(a.h3 + row_of(k) * (196 * C) + 192 * C + lane * 4),
+            (const __attribute__((address_space(1))) void*)(in_map + row_of(k) * (196 * C) + 192 * C + lane * 4),
             (__attribute__((address_space(3))) void*)(la + (k & 1) * (4 * C)), 16, 0, 0);
     };
     // (run by the FORWARD waves after their GEMM: the trace showed the gather waves as the step's critical path -- 10.9 k cycles with
     // this work against 5.3 k for a forward wave; lt = thread index inside the group of waves that shares the piece)
     auto left_fwd = [&](int k, int lt) {
         const float* A = la + (k & 1) * (4 * C);
+        if constexpr (BN) {
+            // wave w2 (0 / 1) takes positions 192 + 2 w2 and + 1: lane = channel converts the two pre-activations once (25 kappa threads
+            // per position would each convert all 64), parks them in LDS and notes the gate bits; the wave then reads its own image
+            // (LDS operations of one wave complete in order) for the 2 x 25 dot products
+            const int w2 = lt >> 6, c = lt & 63;
+            float* img = lh + w2 * (2 * C);
+            const float mu = sBN[c], rs = sBN[C + c], gm = sBN[2 * C + c], be = sBN[3 * C + c];
+            unsigned bits = 0;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const float t = __builtin_fmaf((A[(2 * w2 + p) * C + c] - mu) * rs, gm, be);
+                img[p * C + c] = t > 0.f ? t : 0.f;
+                bits |= (t > 0.f ? 1u : 0u) << p;
+            }
+            lmaskb[((k % 3) * 2 + w2) * C + c] = bits;
+            if (c < 50) {
+                const int ql = c / 25, kappa = c - ql * 25;
+                float acc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < C / 8; ++kk) {
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(img + ql * C + kk * 8);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(img + ql * C + kk * 8 + 4);
+                    const f32x4 w0 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + kappa) * 4);
+                    const f32x4 w1 = *reinterpret_cast<const f32x4*>(sWf + (kk * 64 + 32 + kappa) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc = __builtin_fmaf(h0[e], w0[e], acc);
+                        acc = __builtin_fmaf(h1[e], w1[e], acc);
+                    }
+                }
+                sP[(k & 1) * PSZ + (192 + 2 * w2 + ql) * MN_NKP + kappa] = acc;
+            }
+            return;
+        }
         if (lt < C) {                     // ReluGrad bits of the 4 positions, one word per channel (bit p = position 192 + p)
             unsigned w = 0;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) w |= (A[p * C + lt] > 0.f ? 1u : 0u) << p;
+            for (int p = 0; p < 4; ++p) {
+                w |= (A[p * C + lt] > 0.f ? 1u : 0u) << p;
+            }
             lmask[(k % 3) * C + lt] = w;
         }
         if (lt < 100) {                   // P[192 + qp][kappa] = sum_c h[c] F[kappa][c], c in the order of the MFMA k-steps
@@ -919,7 +1046,12 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             sP[(k & 1) * PSZ + (192 + qp) * MN_NKP + kappa] = acc;
         }
     };
-    auto left_bwd = [&](int k, int lt) {  // dH[192 + qp][c] = sum_kappa G[kappa] F[kappa][c], kappa ascending (the MFMA k order)
+    float ls1 = 0.f, ls2 = 0.f;           // BN: backward sums of this thread's (position 192 + qp, channel c) over its rows
+    // BN: the pre-activation of this thread's element of row k.  Fetched at the TOP of the step, before the step's LDS-DMAs: vmcnt
+    // counts in issue order, so a load issued behind them could only be waited for together with them (the whole HBM latency of
+    // the row two steps ahead: measured as +3 k cycles per step on waves 2-5)
+    auto left_pre = [&](int k, int lt) { return a.bn_pre[row_of(k) * (196 * C) + (192 + (lt >> 6)) * C + (lt & 63)]; };
+    auto left_bwd = [&](int k, int lt, float pre) {  // dH[192 + qp][c] = sum_kappa G[kappa] F[kappa][c], kappa ascending (the MFMA k order)
         const int qp = lt >> 6, c = lt & 63;
         const float* pg = sg + (k & 1) * GSZ + (2 * 13) * MN_GWP + 2 * (10 + qp);      // position 192 + qp = (oh 13, ow 10 + qp)
         float acc = 0.f;
@@ -929,8 +1061,10 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             const float wv = sWb[((kappa >> 1) * 64 + (kappa & 1) * 32 + (c & 31)) * (C / 32) + (c >> 5)];
             acc = __builtin_fmaf(gv, wv, acc);
         }
-        const unsigned mw = lmask[(k % 3) * C + c];
-        a.h3[row_of(k) * (196 * C) + (192 + qp) * C + c] = ((mw >> qp) & 1u) ? acc : 0.f;
+        const unsigned mw = BN ? lmaskb[((k % 3) * 2 + (qp >> 1)) * C + c] >> (qp & 1) : lmask[(k % 3) * C + c] >> qp;
+        const float dv = (mw & 1u) ? acc : 0.f;
+        a.h3[row_of(k) * (196 * C) + (192 + qp) * C + c] = dv;
+        if constexpr (BN) { ls1 += dv; ls2 = __builtin_fmaf(dv, (pre - sBN[c]) * sBN[C + c], ls2); }
     };
 
     // ---- the roles run separate loops with the same barrier sequence: sg-zero | prologue | one per step ------------
@@ -969,6 +1103,8 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
         dma_landed_barrier();
         for (int t = 0; t <= n_my; ++t) {
             TR_BEGIN();
+            float lpre = 0.f;
+            if constexpr (BN) { if (wave >= 2 && t >= 1) lpre = left_pre(t - 1, tid - 128); }
             if (t + 1 < n_my) {
                 read_frags(A);                                   // row t+1 (staged one step ago)
                 if (t + 2 < n_my) { stage_row(t + 2); stage_left(t + 2); }     // land during this step
@@ -976,10 +1112,16 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             }
             // positions 192..195: waves 0, 1 their forward entries of row t+1, waves 2-5 their gradients of row t-1
             if (wave < 2) { if (t + 1 < n_my) left_fwd(t + 1, tid); }
-            else if (t >= 1) left_bwd(t - 1, tid - 128);
+            else if (t >= 1) left_bwd(t - 1, tid - 128, lpre);
             TR_MID();
             dma_landed_barrier();
             TR_END(t);
+        }
+        if constexpr (BN) {
+            if (wave >= 2) {              // waves 2..5 = positions 192..195, lane = channel
+                float* rec = a.bn_sums + ((long long)blockIdx.x * 10 + 6 + (wave - 2)) * (2 * C);
+                rec[lane] = ls1; rec[C + lane] = ls2;
+            }
         }
         TR_FLUSH(wave == 0 ? 0 : 3);
     } else if (has_bwd) {
@@ -992,6 +1134,7 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             lds_barrier();                                       // the row stores stay in flight
             TR_END(t);
         }
+        flush_bwd_sums();
         TR_FLUSH(1);
     } else {
         float xv0[4], xv1[4];
@@ -1034,9 +1177,14 @@ void launch_mnist_tail_mfma(const MnistTailArgs& a, hipStream_t s) {
         if (a.pipe_version == 3) {
             const int lds3 = (2 * 196 * MN_NKP + 2 * MN_GR * MN_GWP + 3 * 6 * C + 8 + (C / 8) * 256 + 13 * 64 * (C / 32)) * 4 + 6 * 32 * C * 4 + 6 * 4096 +
                              2 * 4 * C * 4 + 3 * C * 4;
+            const int lds3_bn = (4 * C + 2 * 2 * C + 3 * 2 * C) * 4;      // Batchnorm form: constants, converted images and gate bits of 192..195
             static PerDeviceOnce attr3;
-            if (attr3.need()) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe3_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-            hipLaunchKernelGGL((mnist_tail_pipe3_kernel<64>), dim3(a.pipe), dim3(1024), lds3, s, a);
+            if (attr3.need()) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe3_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mnist_tail_pipe3_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds3 + lds3_bn);
+            }
+            if (a.bn_pre) hipLaunchKernelGGL((mnist_tail_pipe3_kernel<64, true>), dim3(a.pipe), dim3(1024), lds3 + lds3_bn, s, a);
+            else hipLaunchKernelGGL((mnist_tail_pipe3_kernel<64, false>), dim3(a.pipe), dim3(1024), lds3, s, a);
         }
 #ifdef DG_MEASURE
         else if (a.pipe_version == 2) hipLaunchKernelGGL((mnist_tail_pipe2_kernel<64>), dim3(a.pipe), dim3(768), lds, s, a);

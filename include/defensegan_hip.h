@@ -177,7 +177,10 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *   "bn_fused"         with use_bn, where the Batchnorm sums come from.  1: the forward statistics are per-32-row-block column sums taken
  *                      in the producing GEMM's epilogue; 2 (default): so are the backward sums (of dy and dy * xhat) of the layers
  *                      normalised over rows x positions, taken in the epilogue of the GEMM that writes dy (which re-forms the ReLU gate
- *                      and xhat from the layer's pre-activations); 0: separate passes (float64 sums from the first add)
+ *                      and xhat from the layer's pre-activations), and inside the projection loop the MNIST tail takes its Batchnorm form
+ *                      (it reads the last Batchnorm layer's pre-activations, applies relu(bn(.)) itself and leaves that layer's backward
+ *                      sums: the layer's activation image is not written in those steps -- dg_debug_read("act2") then returns the image
+ *                      of the last launch that did write it); 0: separate passes (float64 sums from the first add)
  *   "jobs.slots0/1", "jobs.rate0..2", "jobs.fixed_us"   cost-model parameters
  *   "lr_schedule"      "constant" (default): lr == rec_lr at every step, which is what the reference executes -- the step variable
  *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,

@@ -162,3 +162,35 @@ def test_bn_statistics_from_the_gemm_epilogue(arch, B, R):
     for opts in ({"jobs.min_level": 1, "jobs.tune": 0}, {"jobs.slack": 1e30, "jobs.min_level": 2}, {"jobs.slack": 0.01, "jobs.min_level": 0}):
         y2, l2, d2 = run(opts)
         assert np.array_equal(y2, y1) and np.array_equal(l2, l1) and np.array_equal(d2, d1), opts
+
+
+@pytest.mark.parametrize("B,R,pipe", [(4, 2, 4), (7, 3, 10), (64, 10, 256)])
+def test_bn_mnist_tail_in_its_batchnorm_form(B, R, pipe):
+    """Round 6 (bn_fused = 2): inside the projection loop the MNIST tail reads the PRE-ACTIVATIONS of Generator.3's Batchnorm layer,
+    applies relu(bn(.)) itself (the activation image is never written) and leaves that layer's backward sums (dg_tail_mnist.hip
+    mnist_tail_pipe3_kernel<64, true>; it runs when a launch has >= 2 rows per workgroup of the persistent kernel: `tail_pipe`).
+    Against bn_fused = 1 (forward apply pass + float64 backward statistics pass) on the same inputs: the forward bits are the same
+    expression, the sums differ by float32 rounding -- three loop steps agree to 1e-5 of z's scale; and against the float64 oracle
+    on the smallest case."""
+    x = _targets("mnist", B, 21)
+    z0 = synth.make_z(B * R, 128, seed=22)
+
+    def run(fused):
+        gan, p = make_gan("mnist", gain=2.0, bias_range=0.1, use_bn=True, rec_rr=R, rec_iters=3, rec_lr=1.0)
+        gan.set_option("tail_pipe", pipe)
+        gan.set_option("bn_fused", fused)
+        return gan.reconstruct(x, z_init_val=z0, return_details=True), p
+    o2, p = run(2)
+    o1, _ = run(1)
+    # (batch statistics couple all rows and a ReLU gate at rounding distance flips: most of the batch agrees to 1e-5, a few rows move)
+    np.testing.assert_allclose(o2["loss"], o1["loss"], rtol=5e-3)
+    assert np.median(np.abs(np.asarray(o2["loss"]) / np.asarray(o1["loss"]) - 1.0)) < 2e-5
+    dr = np.abs(np.asarray(o2["rec"]) - np.asarray(o1["rec"]))
+    assert (dr <= 1e-4).mean() >= 0.97 and dr.max() < 1e-2, (float((dr > 1e-4).mean()), float(dr.max()))
+    dz = np.abs(np.asarray(o2["z"]) - np.asarray(o1["z"])).max(axis=1) / np.abs(np.asarray(o1["z"])).max()
+    assert np.median(dz) < 1e-5 and (dz < 1e-3).mean() >= 0.95, np.sort(dz)[-3:]
+    if B * R <= 8:
+        O = _oracle()
+        ref = O.reconstruct(p, x, z0, R, 3, lr=1.0, momentum=0.7, arch="mnist", use_bn=True, dtype=np.float64)
+        np.testing.assert_allclose(o2["loss"], ref["loss"], rtol=2e-3)
+        np.testing.assert_allclose(o2["rec"], ref["rec"], rtol=0, atol=2e-3)

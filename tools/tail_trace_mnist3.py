@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Phase timing of mnist_tail_pipe3_kernel (measurement build, engine option tail_trace): per role (wave 0 forward GEMM, wave 6
 backward GEMM, wave 12 gather) the shader cycles per steady-state step spent between the barriers (work) and inside them (wait).
-    python tools/tail_trace_mnist3.py [B=256] [key=value ...]"""
+    python tools/tail_trace_mnist3.py [B=256] [use_bn=1] [key=value ...]       (use_bn=1: the kernel's Batchnorm form, bn_fused = 2)"""
 import os
 import sys
 
@@ -13,9 +13,11 @@ from defensegan_amd import archs, synth
 from defensegan_amd.gan import dataset_gan_dict
 
 B, R, L = 256, 10, 4
+use_bn = "use_bn=1" in sys.argv[1:]
+sys.argv = [v for v in sys.argv if not v.startswith("use_bn=")]
 a = archs.make_arch("mnist")
-gan = dataset_gan_dict["mnist"](cfg={"USE_BN": False}, test_mode=True, measure=True, rec_rr=R, rec_iters=L, device=0)
-gan.set_weights(synth.make_weights("mnist", seed=1234, gain=2.0))
+gan = dataset_gan_dict["mnist"](cfg={"USE_BN": use_bn}, test_mode=True, measure=True, rec_rr=R, rec_iters=L, device=0)
+gan.set_weights(synth.make_weights("mnist", seed=1234, gain=2.0, use_bn=use_bn, bn_jitter=0.2 if use_bn else 0.0))
 gan.set_option("tail_pipe_version", 3)
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
