@@ -246,6 +246,11 @@ __global__ __launch_bounds__(256) void bn_fold_blocks_kernel(const float* __rest
     }
 }
 
+// mean / rstd (forward) or mean(dy) / mean(dy * xhat) from nblk float block sums.  More than BN_FOLD_RANGES blocks are first folded
+// to that many float64 partials (coalesced over the channels); fewer go to the finalize kernel as they are -- the same additions in
+// the same order (a range would hold one block), one launch less (BN1: 80 blocks at 2560 rows; the MNIST tail: one per workgroup)
+static void stats_from_blocks(const BnArgs& a, const float* block_sums, int nblk, float* stats, int forward, const float* shift, hipStream_t s);
+
 // block sums -> at most BN_FOLD_RANGES float64 partials in a.part; returns the number of ranges
 static int fold_blocks(const BnArgs& a, const float* block_sums, int nblk, hipStream_t s) {
     const int per_range = (nblk + BN_FOLD_RANGES - 1) / BN_FOLD_RANGES;
@@ -255,10 +260,18 @@ static int fold_blocks(const BnArgs& a, const float* block_sums, int nblk, hipSt
     return ranges;
 }
 
-void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift) {
+static void stats_from_blocks(const BnArgs& a, const float* block_sums, int nblk, float* stats, int forward, const float* shift, hipStream_t s) {
+    if (nblk <= BN_FOLD_RANGES) {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3((a.C + 15) / 16), dim3(256), 0, s, block_sums, nblk, (long long)a.rows, a.C, stats, forward, shift);
+        return;
+    }
     const int ranges = fold_blocks(a, block_sums, nblk, s);
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.fstats, 1,
+    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, stats, forward,
                        shift);
+}
+
+void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, int relu, hipStream_t s, const float* shift) {
+    stats_from_blocks(a, block_sums, nblk, a.fstats, 1, shift, s);
     if (relu < 0) return;              // statistics only: the consumer applies relu(bn(.)) itself (the MNIST tail's Batchnorm form)
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
@@ -266,9 +279,7 @@ void launch_bn_forward_from_blocks(const BnArgs& a, const float* block_sums, int
 }
 
 void launch_bn_backward_from_blocks(const BnArgs& a, const float* block_sums, int nblk, hipStream_t s) {
-    const int ranges = fold_blocks(a, block_sums, nblk, s);
-    hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3((a.C + 15) / 16), dim3(256), 0, s, (const double*)a.part, ranges, (long long)a.rows, a.C, a.bstats, 0,
-                       (const float*)nullptr);
+    stats_from_blocks(a, block_sums, nblk, a.bstats, 0, nullptr, s);
     const long long total = (long long)a.rows * a.C;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, a.a, a.xhat, a.fstats,
                        a.bstats, a.scale, total, a.C);

@@ -181,9 +181,9 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         }
     }
     if (part_doubles) HIP_TRY(hipMalloc(&h->bn_part, part_doubles * sizeof(double)));
-    // Batchnorm form of the MNIST tail: 10 records [2][C] per workgroup (dg_tail_mnist.hip mnist_tail_pipe3_kernel<C, true>)
+    // Batchnorm form of the MNIST tail: one record [2][C] per workgroup (dg_tail_mnist.hip mnist_tail_pipe3_kernel<C, true>)
     if (h->arch == DG_ARCH_MNIST28 && h->ai[(size_t)nd - 1].has_bn && h->bn_fused >= 2 && h->tail_pipe > 0) {
-        HIP_TRY(hipMalloc(&h->tail_bn_sums, (size_t)h->tail_pipe * 10 * 2 * (size_t)h->ai[(size_t)nd - 1].bn_C * sizeof(float)));
+        HIP_TRY(hipMalloc(&h->tail_bn_sums, (size_t)h->tail_pipe * 2 * (size_t)h->ai[(size_t)nd - 1].bn_C * sizeof(float)));
         h->tail_bn_sums_wgs = h->tail_pipe;
     }
     h->F1.stats = h->ai[0].block_sums; h->F1.stats_cap = h->ai[0].block_cap;
@@ -623,7 +623,7 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* u
         ProfScope ps(h, g.s, prof, "BNb", 0.0);
         const GemmOp* producer = k + 1 < nd ? &h->Bd[(size_t)k] : nullptr;
         if (!producer && h->tail_left_bn_sums)         // the tail wrote dy and its sums (run_forward of this step)
-            dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->tail_bn_sums, h->tail_bn_sums_wgs * 10, g.s);
+            dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->tail_bn_sums, h->tail_bn_sums_wgs, g.s);
         else if (producer && producer->mode == dg::EPI_MASK_STATS)
             dg::launch_bn_backward_from_blocks(bn_args(h, h->ai[k], g.n_rows), h->ai[k].block_sums, (int)dg::stat_blocks(producer->bplan, g.n_rows), g.s);
         else

@@ -206,7 +206,7 @@ struct dg_handle {
     int tail_bwd_persist = 512;
     int tail_fwd_split = 512;      // CelebA forward tail (64 channels): workgroups of the role-split persistent kernel, two per CU
                                    // (0 = celeba_tail_fwd16_kernel, which also serves NET_DIM 128)
-    float* tail_bn_sums = nullptr; // Batchnorm form of the MNIST tail: [tail_bn_sums_wgs * 10][2][C] backward sums of the last Batchnorm layer
+    float* tail_bn_sums = nullptr; // Batchnorm form of the MNIST tail: [tail_bn_sums_wgs][2][C] backward sums of the last Batchnorm layer
     int tail_bn_sums_wgs = 0;
     bool tail_left_bn_sums = false; // the last run_forward's tail ran in that form (run_backward takes the sums from it)
     int tail_pipe = 256;           // MNIST tail: persistent pipelined kernel, workgroups (0 = fused per-row kernel)

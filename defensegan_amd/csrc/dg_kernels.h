@@ -191,7 +191,7 @@ struct MnistTailArgs {
                          // generation pipelined kernel, which does not reduce it, may run
     // Batchnorm form of the third-generation pipelined kernel (mnist_tail_pipe3_kernel<C, true>; nullptr = plain): the input map is
     // bn_pre, the PRE-ACTIVATIONS of Generator.3's Batchnorm layer (h3 is then written only: da3), with that layer's forward statistics
-    // [2][C] (mean, rstd), scale and offset [C]; bn_sums receives [pipe * 10][2][C] backward sums (dy, dy * xhat) for
+    // [2][C] (mean, rstd), scale and offset [C]; bn_sums receives [pipe][2][C] backward sums (dy, dy * xhat) for
     // launch_bn_backward_from_blocks.  Other kernels of this launcher ignore the fields: callers set them only when that kernel runs
     // (mnist_tail_runs_pipe3)
     const float* bn_pre;

@@ -721,8 +721,8 @@ __global__ __launch_bounds__(768) void mnist_tail_pipe2_kernel(MnistTailArgs a) 
 // relu(bn(.)) to their fragments as they leave LDS (the float expression of bn_apply_fwd_kernel: the activation image is never written
 // or read -- one pass of 2 x 128 MB less per step at 2560 rows), and the backward waves add up that layer's backward sums (dy and
 // dy * xhat per channel, xhat re-formed from the pre-activations they fetch beside their MFMAs) over all their rows; every wave
-// leaves one [2][C] record at the end (MnistTailArgs::bn_sums: 10 per workgroup, 6 tiles + positions 192..195), folded by
-// launch_bn_backward_from_blocks -- the statistics pass of the Batchnorm backward (another 2 x 128 MB) is not run either.
+// leaves one [2][C] record at the end (6 tiles + positions 192..195), added up in LDS to ONE per workgroup (MnistTailArgs::bn_sums), which
+// launch_bn_backward_from_blocks finalizes -- the statistics pass of the Batchnorm backward (another 2 x 128 MB) is not run either.
 template <int C, bool BN>
 __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a) {
     static_assert(C == 64, "64 channels");
@@ -902,10 +902,12 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             }
         }
     };
-    // one [2][C] record of a backward wave: the 8 lanes that share 4 channels hold different rows -- a fixed xor tree over lane bits 3..5
+    // one [2][C] record of a backward wave: the 8 lanes that share 4 channels hold different rows -- a fixed xor tree over lane bits 3..5.
+    // The workgroup's 10 records (6 tiles, positions 192..195) meet in LDS (the P images are dead by then) and leave as ONE
+    float* srec = sP;                     // [10][2][C]
     auto flush_bwd_sums = [&]() {
         if constexpr (BN) {
-            float* rec = a.bn_sums + ((long long)blockIdx.x * 10 + btile) * (2 * C);
+            float* rec = srec + btile * (2 * C);
 #pragma unroll
             for (int u = 0; u < C / 32; ++u) {
 #pragma unroll
@@ -1119,7 +1121,7 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
         }
         if constexpr (BN) {
             if (wave >= 2) {              // waves 2..5 = positions 192..195, lane = channel
-                float* rec = a.bn_sums + ((long long)blockIdx.x * 10 + 6 + (wave - 2)) * (2 * C);
+                float* rec = srec + (6 + (wave - 2)) * (2 * C);
                 rec[lane] = ls1; rec[C + lane] = ls2;
             }
         }
@@ -1156,6 +1158,16 @@ __global__ __launch_bounds__(1024) void mnist_tail_pipe3_kernel(MnistTailArgs a)
             if (t + 1 <= n_my) step(t + 1, xv1, xv0);
         }
         TR_FLUSH(2);
+    }
+    if constexpr (BN) {
+        // (every role has passed the same number of barriers; nobody reads P after the last one)
+        lds_barrier();
+        if (tid < 2 * C) {
+            float acc = 0.f;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) acc += srec[r * (2 * C) + tid];
+            a.bn_sums[(long long)blockIdx.x * (2 * C) + tid] = acc;
+        }
     }
 #undef TR_BEGIN
 #undef TR_MID
