@@ -573,6 +573,15 @@ def main():
         # wall time of the ONE untimed step that carried the stream markers: its kernels' durations (consecutive launches share
         # a marker) add up to it; it is longer than a timed step by what ~8 markers per GD iteration cost (~3 us each)
         roofline["profiled_step_ms"] = round(profiled_step_ms, 3) if profiled_step_ms is not None else None
+        # Row groups (dg_call_row_groups; CelebA's default is 2): the timed region runs them on separate streams, where their
+        # kernels OVERLAP -- a launch's duration there is not its rate.  The marked step runs the SAME launches (row counts, job
+        # lists) one after the other on one stream: `avg_launch_us`, `flop_per_launch` and `traffic` are per launch of ONE group,
+        # `frac` is the kernel alone on the chip; `path_frac` is the timed region's wall clock.
+        row_groups = gan.row_groups(B)
+        roofline["row_groups"] = row_groups
+        roofline["launches"] = ("as in the timed region" if row_groups == 1 else
+                                "the timed region's launches (%d row groups of %d rows each), run one at a time in the marked step; "
+                                "in the timed region the groups' kernels overlap on %d streams" % (row_groups, B * R // row_groups, row_groups))
         cfgno = 4 if args.strong else {"mnist": 1, "fmnist": 2, "celeba": 3}[args.workload]
         if args.strong:
             wl = ("%s whitebox FGSM eps=0.3 (classifier model A, dg_fgsm) evaluation of %d images, L=%d R=%d, projection batch %d, classifier model A "
@@ -587,7 +596,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0,
-                       "parallelism": "shard%d" % world},
+                       "parallelism": "shard%d" % world, "row_groups": row_groups},
             "io": "host (pageable NumPy in, NumPy out: PCIe-inclusive)" if args.host_io else "resident in HBM",
             "build": build_id(),
             # which job lists ran (a timed choice per layer and row count; identical ids = identical lists on every rank)
@@ -606,7 +615,7 @@ def main():
             loss = torch.as_tensor(out["loss"]).view(B, R).min(dim=1).values        # NumPy with --host-io
             res["mean_best_loss"] = round(float(loss.mean().item()), 6)
         if world == 1 and not args.no_cpu_baseline and not args.use_bn:
-            res["cpu_baseline"] = cpu_baseline(arch, params, x[:16].cpu().numpy(), R, L)
+            res["cpu_baseline"] = cpu_baseline(arch, params, x[:64].cpu().numpy(), R, L)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()

@@ -31,6 +31,7 @@ SYMBOLS = [
     ("dg_weights_complete", _i, [_vp]),
     ("dg_reconstruct", _i, [_vp, _vp, _vp, _u64, _i64, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     ("dg_prepare", _i, [_vp, _i, _i, _vp]),
+    ("dg_call_row_groups", _i, [_vp, _i, _i]),
     ("dg_generate", _i, [_vp, _vp, _i, _vp, _vp]),
     ("dg_loss_grad", _i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("dg_init_latents", _i, [_vp, _vp, _i64, _u64, _i64, _f, _vp]),

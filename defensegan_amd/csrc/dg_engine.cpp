@@ -383,12 +383,14 @@ int split_groups(const dg_handle* h, int B, int R, RowGroup* grp) {
     const int n_rows = B * R;
     int ngroups = 1;
     grp[0].row0 = 0; grp[0].n_rows = n_rows;
-    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows && h->prof_stride == 0) {
+    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows) {
         ngroups = h->two_streams < B ? h->two_streams : B;
         if (ngroups > dg_handle::kMaxGroups) ngroups = dg_handle::kMaxGroups;
         int b_done = 0;
         for (int gi = 0; gi < ngroups; ++gi) {
-            const int nb = (B - b_done + (ngroups - gi) - 1) / (ngroups - gi);     // images of this group
+            int nb = (B - b_done + (ngroups - gi) - 1) / (ngroups - gi);           // images of this group
+            if (ngroups == 2 && gi == 0 && h->two_stream_split > 0 && h->two_stream_split < 100)
+                nb = std::min(B - 1, std::max(1, (B * h->two_stream_split + 50) / 100));
             grp[gi].row0 = b_done * R;
             grp[gi].n_rows = nb * R;
             b_done += nb;
@@ -804,6 +806,10 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
                   {"Generator.5", nd, 1, 14, 28, 2, ""}};
     } else {
         h->img_h = 64; h->img_c = 3;
+        // Two row groups on two streams by default (round 6, profiles/r06_ab_celeba_row_groups.txt: +2.0 ... +2.9 % at 1280 rows on
+        // three boxes; 3 / 4 groups +0.4 / +0.0 %; unequal halves lose).  Its gather-bound tails (12 % of a step at ~0.6 of the matrix
+        // pipe) run beside the other group's GEMMs.  MNIST loses 0.9 % with two groups and keeps one.
+        h->two_streams = 2;
         h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 8, 0, "Generator.BN2"}, {"Generator.3", 2 * nd, nd, 8, 16, 0, "Generator.BN3"},
                   {"Generator.5", nd, nd, 16, 32, 1, ""}, {"Generator.6", nd, 3, 32, 64, 2, ""}};
     }
@@ -1063,8 +1069,11 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         for (int gj = 0; gj < gi; ++gj) seen = seen || grp[gj].n_rows == grp[gi].n_rows;
         if (!seen) { rc = clear_pair_counters(h, grp[gi].n_rows, s); if (rc) return rc; }
     }
-    if (ngroups > 1) {
-        for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = h->side_stream[gi - 1];
+    // (while the per-launch profile is on, the groups run one after the other on the caller's stream: the same launches -- row
+    // counts, job lists -- as the concurrent form, each alone on the chip, so that a launch's duration is its rate)
+    const bool forked = ngroups > 1 && h->prof_stride == 0;
+    for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = forked ? h->side_stream[gi - 1] : s;
+    if (forked) {
         HIP_TRY(hipEventRecord(h->ev_fork, s));
         for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
     }
@@ -1095,7 +1104,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         rc = enqueue_steps(h, x, R, L, lr, momentum, grp, ngroups);
         if (rc) return rc;
     }
-    for (int gi = 1; gi < ngroups; ++gi) {
+    for (int gi = 1; forked && gi < ngroups; ++gi) {
         HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
         HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
     }
@@ -1104,6 +1113,14 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     if (out_z) HIP_TRY(hipMemcpyAsync(out_z, h->z, zbytes, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipGetLastError());
     return DG_OK;
+}
+
+int dg_call_row_groups(dg_handle* h, int B, int R) {
+    if (check_ready(h)) return -1;
+    int n_rows = 0;
+    if (check_rows(B, R, &n_rows)) return -1;
+    RowGroup grp[dg_handle::kMaxGroups];
+    return split_groups(h, B, R, grp);
 }
 
 int dg_prepare(dg_handle* h, int B, int R, void* stream) {
@@ -1116,7 +1133,7 @@ int dg_prepare(dg_handle* h, int B, int R, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     rc = prepare_call(h, B, R, s);
     if (rc) return rc;
-    // dg_loss_grad / dg_generate and the profiled (single-group) form of the same shape run all rows as one group
+    // dg_loss_grad / dg_generate run all rows as one group
     rc = prepare_rows(h, n_rows, &n_rows, 1, s);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(s));

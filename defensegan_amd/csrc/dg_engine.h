@@ -221,6 +221,7 @@ struct dg_handle {
     // overlap beyond their launch ends, and the half-size launches are less efficient); CelebA +0.9 %; 500 rows -13 %.
     int two_streams = 0;
     int two_stream_min_rows = 1024;
+    int two_stream_split = 0;      // two groups: percent of the images in the first (0 = halves)
     static constexpr int kMaxGroups = 8;
     hipStream_t side_stream[kMaxGroups - 1] = {};
     hipEvent_t ev_fork = nullptr, ev_join[kMaxGroups - 1] = {};

@@ -64,6 +64,10 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         h->lr_intended = v == "intended";
         return DG_OK;
     }
+    if (k == "two_stream_split") {       // two row groups: percent of the images in the first one (0 = halves)
+        h->two_stream_split = atoi(value);
+        return DG_OK;
+    }
     if (k == "two_stream_min_rows") {
         h->two_stream_min_rows = atoi(value);
         return DG_OK;

@@ -284,6 +284,17 @@ class DefenseGANBase(object):
             return out
         return rec.cpu().numpy() if was_numpy else rec
 
+    def row_groups(self, batch_size=None) -> int:
+        """Number of row groups a ``reconstruct`` of ``batch_size`` images runs as (dg_call_row_groups; option ``two_streams``)."""
+        h = self._ensure_handle()
+        if not self.initialized:
+            raise _native.NativeError("generator weights not loaded (load_generator / set_weights)")
+        lib = self._lib()
+        n = lib.dg_call_row_groups(h, int(batch_size or self.test_batch_size), int(self.rec_rr))
+        if n < 0:
+            raise _native.NativeError(lib.dg_last_error().decode())
+        return int(n)
+
     def prepare(self, batch_size=None):
         """Builds everything ``reconstruct`` needs for batches of ``batch_size`` images (workspace, the per-layer job lists
         chosen by timing) ahead of the first call -- the counterpart of the reference building its static graph for

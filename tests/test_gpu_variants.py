@@ -98,7 +98,10 @@ BITWISE = {
     "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
                {"jobs.prio": 2}, {"jobs.prio": 0}, {"jobs.pair_kernel": 2},
                {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300},
-               {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}, {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 3}],
+               {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}, {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 3},
+               # row groups on streams (CelebA's default for calls of >= 1024 rows), 2 and 3 of them, unequal halves
+               {"two_streams": 2, "two_stream_min_rows": 64}, {"two_streams": 3, "two_stream_min_rows": 64},
+               {"two_streams": 2, "two_stream_min_rows": 64, "two_stream_split": 60}],
 }
 
 
@@ -121,6 +124,35 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
         got = _run(g2, x, z0)
         for k in ("rec", "idx", "loss", "z"):
             assert np.array_equal(got[k], ref[k]), (opts, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+def test_celeba_calls_of_1024_rows_or_more_run_as_two_row_groups_with_the_same_bits():
+    """Round 6: CelebA's default is two row groups on two streams for calls of >= 1024 latent rows (dg_call_row_groups; +2-3 % at
+    configs[3]'s 1280 rows, profiles/r06_ab_celeba_row_groups.txt); MNIST and use_bn keep one.  The split is by whole images and
+    rows are independent: the same bits as one group -- also while the per-launch profile is on, when the groups run one after
+    the other on the caller's stream (bench.py's marked step), with every layer then sampled once per group."""
+    a = archs.make_arch("celeba")
+    B, R = 104, 10
+    gan, p = _make("celeba", R=R, L=2)
+    assert gan.row_groups(B) == 2 and gan.row_groups(128) == 2 and gan.row_groups(102) == 1
+    gm, _ = _make("mnist", R=R, L=2)
+    assert gm.row_groups(256) == 1
+    rs = np.random.RandomState(31)
+    x = rs.uniform(a.in_lo, a.in_hi, size=(B,) + tuple(a.image_dim)).astype(np.float32)
+    z0 = synth.make_z(B * R, 128, seed=32)
+    ref = _run(gan, x, z0)
+    g1, _ = _make("celeba", R=R, L=2)
+    g1.set_option("two_streams", 0)
+    assert g1.row_groups(B) == 1
+    one = _run(g1, x, z0)
+    gan.profile_reset()
+    gan.profile_enable(1)
+    marked = _run(gan, x, z0)
+    gan.profile_enable(0)
+    prof = {q["name"].partition("@")[0]: q["launches"] for q in gan.profile_read()}
+    assert prof["F5"] == 2 * 2 and prof["B5"] == 2 * 1, prof          # L = 2: two forwards, one backward, per group
+    for k in ("rec", "idx", "loss", "z"):
+        assert np.array_equal(one[k], ref[k]) and np.array_equal(marked[k], ref[k]), k
 
 
 @pytest.mark.parametrize("arch,B,R", [("mnist", 50, 10), ("celeba", 30, 10)])

@@ -11,6 +11,11 @@ candidate job lists (dg_prepare) are mixed into every symbol's Calls as well.  A
 
 With the JSON line bench.py printed in the same run, each group is labelled with the layer whose hipEvent average (bench.py's
 "kernels" rows, same symbol) is closest to the group's average.
+
+Row groups on several streams (CelebA's default, option two_streams): the same launch runs OVERLAPPED with the other group's
+kernels in the timed region and ALONE in bench.py's marked step.  A launch counts as overlapped when another kernel of the
+trace runs during more than 10 % of its duration; the two kinds get separate rows ("<layer> [overlapped]": its duration is not
+a rate) -- bench.py's roofline is checked against the rows of the launches that ran alone.
 """
 import collections
 import csv
@@ -54,29 +59,52 @@ def main():
         # (under the profiler the hipEvent markers add 3-6 us to a launch -- 20+ us to the update kernel in one traced run: relative
         # tolerance for the long launches, absolute for the short ones)
         return best["name"] if abs(best["avg_us"] * 1e3 - mean_ns) <= max(0.25 * mean_ns, 7000.0) else ""
-    groups = collections.defaultdict(list)
+    launches = []
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             grid = int(row["Grid_Size_X"]) // max(1, int(row["Workgroup_Size_X"]))
-            key = (short(row["Kernel_Name"]), grid, int(row["LDS_Block_Size"]))
-            groups[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            launches.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), (short(row["Kernel_Name"]), grid, int(row["LDS_Block_Size"]))))
+    launches.sort()
+    # time each launch shares with other kernels: sweep in start order, `active` = launches that have not ended yet
+    shared = [0] * len(launches)
+    active = []
+    for i, (st, en, _) in enumerate(launches):
+        active = [j for j in active if launches[j][1] > st]
+        for j in active:
+            ov = min(en, launches[j][1]) - st
+            if ov > 0:
+                shared[i] += ov
+                shared[j] += ov
+        active.append(i)
+    groups = collections.defaultdict(list)
+    for (st, en, key), sh in zip(launches, shared):
+        groups[key + (sh > 0.10 * max(1, en - st),)].append(en - st)
     folded = collections.defaultdict(list)
     rows = []
-    for (name, grid, lds), d in groups.items():
+    alone_mean = {}
+    for (name, grid, lds, ovl), d in groups.items():
+        if not ovl:
+            alone_mean[(name, grid, lds)] = sum(d) / len(d)
+    for (name, grid, lds, ovl), d in groups.items():
         if len(d) < min_calls and "gemm_batched_kernel" in name:
             folded[name].extend(d)
+        elif ovl:
+            # labelled through the same launch's ALONE rows (its own average says nothing about which layer it is)
+            lay = layer_of(name, alone_mean[(name, grid, lds)]) if (name, grid, lds) in alone_mean and grid else ""
+            rows.append((name, grid, lds, d, (lay + " [overlapped]").strip()))
         else:
-            rows.append((name, grid, lds, d))
+            rows.append((name, grid, lds, d, None))
     for name, d in folded.items():
-        rows.append((name + " [candidate job lists, not kept]", 0, 0, d))
-    total = sum(sum(d) for _, _, _, d in rows)
+        rows.append((name + " [candidate job lists, not kept]", 0, 0, d, None))
+    total = sum(sum(r[3]) for r in rows)
     w = csv.writer(sys.stdout)
     w.writerow(["Layer", "Kernel", "Workgroups", "LDS_bytes", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-    for name, grid, lds, d in sorted(rows, key=lambda r: -sum(r[3])):
+    for name, grid, lds, d, label in sorted(rows, key=lambda r: -sum(r[3])):
         n, s = len(d), sum(d)
         mean = s / n
         sd = math.sqrt(sum((x - mean) ** 2 for x in d) / n)
-        w.writerow([layer_of(name, mean) if grid else "", name, grid, lds, n, s, round(mean, 1), round(100.0 * s / total, 2), min(d), max(d), round(sd, 1)])
+        lay = label if label is not None else (layer_of(name, mean) if grid else "")
+        w.writerow([lay, name, grid, lds, n, s, round(mean, 1), round(100.0 * s / total, 2), min(d), max(d), round(sd, 1)])
 
 
 if __name__ == "__main__":
