@@ -379,11 +379,26 @@ struct RowGroup {
 };
 
 // Row groups of a call over B images x R restarts (whole images per group; the streams are assigned by the caller).
-int split_groups(const dg_handle* h, int B, int R, RowGroup* grp) {
+int split_groups(const dg_handle* h, int B, int R, RowGroup* grp, int force = -1);
+
+// may a call of B x R run as several row groups at all?
+bool groups_eligible(const dg_handle* h, int B, int R) {
+    return h->two_streams > 1 && !h->use_bn && B * R >= h->two_stream_min_rows && B > 1;
+}
+
+// force: -1 = what the call runs as (with two_streams_auto: the timed choice of this shape, ONE group while there is none),
+// 1 = one group, > 1 = the concurrent form
+int split_groups(const dg_handle* h, int B, int R, RowGroup* grp, int force) {
     const int n_rows = B * R;
     int ngroups = 1;
     grp[0].row0 = 0; grp[0].n_rows = n_rows;
-    if (h->two_streams > 1 && !h->use_bn && n_rows >= h->two_stream_min_rows) {
+    bool several = groups_eligible(h, B, R);
+    if (several && force == 1) several = false;
+    if (several && force < 0 && h->two_streams_auto) {
+        const auto it = h->group_choice.find(std::make_pair(B, R));
+        several = it != h->group_choice.end() && it->second > 1;
+    }
+    if (several) {
         ngroups = h->two_streams < B ? h->two_streams : B;
         if (ngroups > dg_handle::kMaxGroups) ngroups = dg_handle::kMaxGroups;
         int b_done = 0;
@@ -454,9 +469,31 @@ int prepare_rows(dg_handle* h, int64_t cap_rows, const int* rows, int n, hipStre
     return DG_OK;
 }
 
-// prepare_rows for a projection call of B images x R restarts: its row groups' sizes
+int time_group_forms(dg_handle* h, int B, int R, hipStream_t s, int* best);
+
+// prepare_rows for a projection call of B images x R restarts: its row groups' sizes.  With two_streams_auto a shape that may run
+// as several groups is prepared in both forms once and the faster form is kept (timed: a few loop steps of each, alternating)
 int prepare_call(dg_handle* h, int B, int R, hipStream_t s) {
     RowGroup grp[dg_handle::kMaxGroups];
+    if (h->two_streams_auto && groups_eligible(h, B, R) && !h->group_choice.count(std::make_pair(B, R))) {
+        int rows[dg_handle::kMaxGroups];
+        for (int form : {1, h->two_streams}) {
+            const int ngf = split_groups(h, B, R, grp, form);
+            for (int gi = 0; gi < ngf; ++gi) rows[gi] = grp[gi].n_rows;
+            const int rc = prepare_rows(h, (int64_t)B * R, rows, ngf, s);
+            if (rc) return rc;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return fail(DG_E_STATE, "this call shape has not been prepared and the stream is being captured: call dg_prepare(B, R) "
+                                    "before the capture (it times the one-group and the %d-group form of the call)", h->two_streams);
+        }
+        int best = 1;
+        const int rc = time_group_forms(h, B, R, s, &best);
+        if (rc) return rc;
+        h->group_choice[std::make_pair(B, R)] = best;
+    }
     const int ng = split_groups(h, B, R, grp);
     int rows[dg_handle::kMaxGroups];
     for (int gi = 0; gi < ng; ++gi) rows[gi] = grp[gi].n_rows;
@@ -699,6 +736,68 @@ int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float mo
     return DG_OK;
 }
 
+// enqueue_steps on the call's row groups: several groups run on the engine's side streams, forked off the caller's stream and joined
+// to it again.  (While the per-launch profile is on, the groups run one after the other on the caller's stream: the same launches
+// -- row counts, job lists -- as the concurrent form, each alone on the chip, so that a launch's duration is its rate.)
+int run_groups(dg_handle* h, const float* x, int R, int L, float lr, float momentum, hipStream_t s, RowGroup* grp, int ngroups) {
+    const bool forked = ngroups > 1 && h->prof_stride == 0;
+    grp[0].s = s;
+    for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = forked ? h->side_stream[gi - 1] : s;
+    if (forked) {
+        HIP_TRY(hipEventRecord(h->ev_fork, s));
+        for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
+    }
+    const int rc = enqueue_steps(h, x, R, L, lr, momentum, grp, ngroups);
+    if (rc) return rc;
+    for (int gi = 1; forked && gi < ngroups; ++gi) {
+        HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
+        HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
+    }
+    return DG_OK;
+}
+
+// One group or h->two_streams groups for calls of B x R?  Nine loop steps of each form on zeroed latents and images (the launches
+// do not depend on the values), three times alternating, the best time of each; the concurrent form is kept when it is at least
+// 1 % faster.  Runs once per call shape, from prepare_call (blocking, like the timing of the job lists).
+int time_group_forms(dg_handle* h, int B, int R, hipStream_t s, int* best) {
+    const int n_rows = B * R;
+    float* xt = nullptr;
+    HIP_TRY(hipMalloc(&xt, (size_t)B * h->P * sizeof(float)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = DG_OK;
+    const int saved_prof = h->prof_stride;
+    h->prof_stride = 0;
+    auto done = [&](int r) { h->prof_stride = saved_prof; if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); (void)hipFree(xt); return r; };
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return done(fail(DG_E_HIP, "hipEventCreate failed"));
+    if (hipMemsetAsync(xt, 0, (size_t)B * h->P * sizeof(float), s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
+    const int forms[2] = {1, h->two_streams};
+    double t[2] = {1e30, 1e30};
+    const size_t zbytes = (size_t)n_rows * h->latent * sizeof(float);
+    for (int rep = 0; rep < 3; ++rep)
+        for (int f = 0; f < 2; ++f) {
+            if (hipMemsetAsync(h->z, 0, zbytes, s) != hipSuccess || hipMemsetAsync(h->m, 0, zbytes, s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
+            if (update_folds(h) && hipMemsetAsync(h->upd_count, 0, (size_t)(n_rows / 32 + 16) * sizeof(unsigned), s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
+            RowGroup grp[dg_handle::kMaxGroups];
+            const int ng = split_groups(h, B, R, grp, forms[f]);
+            for (int gi = 0; gi < ng; ++gi) {
+                bool seen = false;
+                for (int gj = 0; gj < gi; ++gj) seen = seen || grp[gj].n_rows == grp[gi].n_rows;
+                if (!seen) { rc = clear_pair_counters(h, grp[gi].n_rows, s); if (rc) return done(rc); }
+            }
+            (void)hipEventRecord(e0, s);
+            rc = run_groups(h, xt, R, 9, 0.f, 0.7f, s, grp, ng);
+            if (rc) return done(rc);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) return done(fail(DG_E_HIP, "the timed loop steps failed: %s", hipGetErrorString(hipGetLastError())));
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (rep > 0 && ms < t[f]) t[f] = ms;                   // (the first round warms both forms up)
+        }
+    *best = t[1] < 0.99 * t[0] ? forms[1] : 1;
+    h->group_timing_ms[0] = t[0]; h->group_timing_ms[1] = t[1];
+    return done(DG_OK);
+}
+
 // Graph of enqueue_steps for one call shape, reading the images from h->xbuf; nullptr = use the eager path.
 hipGraphExec_t loop_graph(dg_handle* h, int B, int R, int L, float lr, float momentum) {
     for (auto it = h->graphs.begin(); it != h->graphs.end();) {
@@ -806,10 +905,12 @@ int dg_create(int arch, int latent_dim, int net_dim, int use_bn, int device, dg_
                   {"Generator.5", nd, 1, 14, 28, 2, ""}};
     } else {
         h->img_h = 64; h->img_c = 3;
-        // Two row groups on two streams by default (round 6, profiles/r06_ab_celeba_row_groups.txt: +2.0 ... +2.9 % at 1280 rows on
-        // three boxes; 3 / 4 groups +0.4 / +0.0 %; unequal halves lose).  Its gather-bound tails (12 % of a step at ~0.6 of the matrix
-        // pipe) run beside the other group's GEMMs.  MNIST loses 0.9 % with two groups and keeps one.
+        // Two row groups on two streams where that is faster (round 6, profiles/r06_ab_celeba_row_groups.txt: +2.0 ... +2.9 % at
+        // configs[3]'s 1280 rows on three boxes -- the gather-bound tails, 12 % of a step at ~0.6 of the matrix pipe, run beside the
+        // other group's GEMMs -- +1.2 % at 2560, nothing at 1600 / 1920 / 3200, -4.5 % at 5120): a timed choice per call shape
+        // (prepare_call).  3 / 4 groups and unequal halves lose; MNIST loses 0.9 % with two groups and keeps one.
         h->two_streams = 2;
+        h->two_streams_auto = 1;
         h->dec = {{"Generator.2", 4 * nd, 2 * nd, 4, 8, 0, "Generator.BN2"}, {"Generator.3", 2 * nd, nd, 8, 16, 0, "Generator.BN3"},
                   {"Generator.5", nd, nd, 16, 32, 1, ""}, {"Generator.6", nd, 3, 32, 64, 2, ""}};
     }
@@ -1069,14 +1170,7 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         for (int gj = 0; gj < gi; ++gj) seen = seen || grp[gj].n_rows == grp[gi].n_rows;
         if (!seen) { rc = clear_pair_counters(h, grp[gi].n_rows, s); if (rc) return rc; }
     }
-    // (while the per-launch profile is on, the groups run one after the other on the caller's stream: the same launches -- row
-    // counts, job lists -- as the concurrent form, each alone on the chip, so that a launch's duration is its rate)
-    const bool forked = ngroups > 1 && h->prof_stride == 0;
-    for (int gi = 1; gi < ngroups; ++gi) grp[gi].s = forked ? h->side_stream[gi - 1] : s;
-    if (forked) {
-        HIP_TRY(hipEventRecord(h->ev_fork, s));
-        for (int gi = 1; gi < ngroups; ++gi) HIP_TRY(hipStreamWaitEvent(grp[gi].s, h->ev_fork, 0));
-    }
+
     // Small prepared shapes replay a captured graph of the loop instead of enqueuing its ~8 L launches one by one
     bool replayed = false;
     if (h->graph_max_rows > 0 && n_rows <= h->graph_max_rows && !h->graph_broken && h->prof_stride == 0 && ngroups == 1 &&
@@ -1101,12 +1195,8 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
         }
     }
     if (!replayed) {
-        rc = enqueue_steps(h, x, R, L, lr, momentum, grp, ngroups);
+        rc = run_groups(h, x, R, L, lr, momentum, s, grp, ngroups);
         if (rc) return rc;
-    }
-    for (int gi = 1; forked && gi < ngroups; ++gi) {
-        HIP_TRY(hipEventRecord(h->ev_join[gi - 1], grp[gi].s));
-        HIP_TRY(hipStreamWaitEvent(s, h->ev_join[gi - 1], 0));
     }
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));

@@ -220,6 +220,9 @@ struct dg_handle {
     // slower with 3+ (a queue only gets workgroup slots as the other's kernel retires them, so two MFMA-bound kernels do not
     // overlap beyond their launch ends, and the half-size launches are less efficient); CelebA +0.9 %; 500 rows -13 %.
     int two_streams = 0;
+    int two_streams_auto = 0;      // 1: whether a call shape runs as ONE group or as two_streams groups is timed once per shape (prepare_call)
+    std::map<std::pair<int, int>, int> group_choice;   // (B, R) -> number of row groups that timing chose
+    double group_timing_ms[2] = {0.0, 0.0};            // the last timing: nine loop steps as one group / as two_streams groups
     int two_stream_min_rows = 1024;
     int two_stream_split = 0;      // two groups: percent of the images in the first (0 = halves)
     static constexpr int kMaxGroups = 8;

@@ -44,7 +44,10 @@ static int set_option(dg_handle* h, const char* key, const char* value);
 int dg_set_option(dg_handle* h, const char* key, const char* value) {
     if (!h || !key || !value) return fail(DG_E_INVALID, "null argument");
     const int rc = set_option(h, key, value);
-    if (rc == DG_OK) ++h->list_epoch;    // an accepted option: captured loops are rebuilt on their next use (a refused one changes nothing)
+    if (rc == DG_OK) {
+        ++h->list_epoch;                 // an accepted option: captured loops are rebuilt on their next use (a refused one changes nothing)
+        h->group_choice.clear();         // ... and the one-group / several-groups choice of every call shape is timed again
+    }
     return rc;
 }
 
@@ -53,8 +56,11 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
     if (k == "two_streams") {
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());
-        h->two_streams = atoi(value);          // number of concurrent row groups (0/1 = off, 2..8)
-        if (h->two_streams == 1) h->two_streams = 2;   // historic meaning of "1": two groups
+        // number of concurrent row groups (0 = off, 2..8; historic "1" = two), or "auto": two groups where timing the call shape
+        // finds them faster (CelebA's default)
+        h->two_streams_auto = std::string(value) == "auto";
+        h->two_streams = h->two_streams_auto ? 2 : atoi(value);
+        if (h->two_streams == 1) h->two_streams = 2;
         drop_job_lists(h);                     // a list's K-pair scratch is sized by the number of groups that may launch it at once
         return DG_OK;
     }

@@ -112,7 +112,8 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
  */
 int dg_prepare(dg_handle* h, int B, int R, void* stream);
 /* Number of row groups a dg_reconstruct call of B images x R restarts runs as (1, or option "two_streams" when the call is large
- * enough: the groups are whole images, run concurrently on the engine's own streams forked from / joined to the caller's, and the
+ * enough -- with "auto" the timed choice of this shape, which exists once the shape has been prepared or called; 1 before that:
+ * the groups are whole images, run concurrently on the engine's own streams forked from / joined to the caller's, and the
  * results do not depend on the split); -1 on an invalid shape (dg_last_error). */
 int dg_call_row_groups(dg_handle* h, int B, int R);
 
@@ -190,9 +191,11 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      of its decay is never advanced (gan.py:362-386, 416-417); "intended": the schedule its code asks for,
  *                      tf.train.exponential_decay(rec_lr, k, ceil(0.8 * rec_iters), 0.1, staircase=True) (base_model.py:186-192)
  *   "nsplit"           split-K factor of the Linear backward (default 16)
- *   "two_streams"      number of concurrent row groups (0/1 = off, 2..8) of calls with at least "two_stream_min_rows" (1024) latent
- *                      rows.  Default 2 for CelebA (+2-3 % at 1280 rows: its gather-bound tails run beside the other group's GEMMs),
- *                      0 for MNIST (-0.9 %).  Results are bit-identical either way (rows are independent).  "two_stream_split": two
+ *   "two_streams"      number of concurrent row groups (0 = off, 2..8) of calls with at least "two_stream_min_rows" (1024) latent
+ *                      rows, or "auto": two groups for the call shapes where that is faster -- timed once per (B, R) when the shape
+ *                      is prepared (nine loop steps of each form, three times; kept when >= 1 % faster).  Default "auto" for CelebA
+ *                      (+2-3 % at 1280 rows: its gather-bound tails run beside the other group's GEMMs; -4.5 % at 5120), 0 for
+ *                      MNIST (-0.9 %).  Results are bit-identical either way (rows are independent).  "two_stream_split": two
  *                      groups, percent of the images in the first (default halves; unequal halves measured slower).  While the
  *                      per-launch profile is on (dg_profile_enable) the groups run one after the other on the caller's stream
  *   "latent_turn"      1 (default): Linear backward / forward on the weight-stationary kernels (dg_linear.hip) where the shapes

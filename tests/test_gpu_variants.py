@@ -127,15 +127,22 @@ def test_launch_shape_variants_are_bit_identical(arch, B, R):
 
 
 def test_celeba_calls_of_1024_rows_or_more_run_as_two_row_groups_with_the_same_bits():
-    """Round 6: CelebA's default is two row groups on two streams for calls of >= 1024 latent rows (dg_call_row_groups; +2-3 % at
-    configs[3]'s 1280 rows, profiles/r06_ab_celeba_row_groups.txt); MNIST and use_bn keep one.  The split is by whole images and
+    """Round 6: CelebA calls of >= 1024 latent rows run as two row groups on two streams where timing the call shape finds that
+    faster (option two_streams = "auto", dg_call_row_groups; +2-3 % at configs[3]'s 1280 rows, profiles/r06_ab_celeba_row_groups.txt);
+    MNIST and use_bn keep one.  The split is by whole images and
     rows are independent: the same bits as one group -- also while the per-launch profile is on, when the groups run one after
     the other on the caller's stream (bench.py's marked step), with every layer then sampled once per group."""
     a = archs.make_arch("celeba")
     B, R = 104, 10
     gan, p = _make("celeba", R=R, L=2)
+    # default "auto": one or two groups is timed when the shape is prepared (one group until then, always one below 1024 rows)
+    assert gan.row_groups(B) == 1 and gan.row_groups(102) == 1
+    gan.prepare(B)
+    assert gan.row_groups(B) in (1, 2) and gan.row_groups(102) == 1
+    gan.set_option("two_streams", 2)                                  # from here on: two groups, not a timed choice
     assert gan.row_groups(B) == 2 and gan.row_groups(128) == 2 and gan.row_groups(102) == 1
     gm, _ = _make("mnist", R=R, L=2)
+    gm.prepare(256)
     assert gm.row_groups(256) == 1
     rs = np.random.RandomState(31)
     x = rs.uniform(a.in_lo, a.in_hi, size=(B,) + tuple(a.image_dim)).astype(np.float32)
