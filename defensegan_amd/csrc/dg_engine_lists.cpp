@@ -1,6 +1,7 @@
 // Job lists of the engine (dg_engine.h): building and TIMING the candidate lists of a layer (get_jobs), their K-pair scratch,
 // the fragment-order lists, and the tuning export / import of the C ABI.
 #include "dg_engine.h"
+#include <cstring>
 
 #pragma GCC visibility push(hidden)
 namespace dge {
@@ -477,6 +478,11 @@ int64_t dg_export_tuning(dg_handle* h, char* buf, int64_t cap) {
     snprintf(line, sizeof line, "dgtune 1 arch %d latent %d net_dim %d use_bn %d nsplit %d cus %d\n", h->arch, h->latent, h->net_dim,
              h->use_bn, h->nsplit, h->cu_count);
     out += line;
+    // the timed one-group / several-groups choice of every call shape (option two_streams = "auto"): "groups B R n"
+    for (const auto& kv : h->group_choice) {
+        snprintf(line, sizeof line, "groups %d %d %d\n", kv.first.first, kv.first.second, kv.second);
+        out += line;
+    }
     auto dump = [&](const GemmOp& op) {
         for (const JobList& jl : op.jobs) {
             dg::TuneRecord r;
@@ -513,6 +519,15 @@ int dg_import_tuning(dg_handle* h, const char* text) {
     HIP_TRY(hipDeviceSynchronize());      // lists that are replaced may still be in use by queued launches
     int n_imported = 0;
     for (;;) {
+        while (*p == '\n' || *p == ' ' || *p == '\r' || *p == '\t') ++p;
+        if (std::strncmp(p, "groups ", 7) == 0) {          // a call shape's row-group choice: installed instead of being timed again
+            int gb = 0, gr = 0, gn = 0, gu = 0;
+            if (sscanf(p, "groups %d %d %d%n", &gb, &gr, &gn, &gu) != 3 || gb < 1 || gr < 1 || gn < 1 || gn > dg_handle::kMaxGroups)
+                return fail(DG_E_INVALID, "malformed row-group record near '%.40s'", p);
+            h->group_choice[std::make_pair(gb, gr)] = gn;
+            p += gu;
+            continue;
+        }
         dg::TuneRecord r;
         if (!dg::parse_tune_record(&p, &r)) {
             if (*p) return fail(DG_E_INVALID, "malformed tuning record near '%.40s'", p);

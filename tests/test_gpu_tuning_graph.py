@@ -78,6 +78,26 @@ def test_tuning_cache_file_hands_the_choice_to_the_next_process(tmp_path):
     assert ids[0] == ids[1] == tuning_text_id(open(cache).read())
 
 
+def test_the_row_group_choice_of_a_call_shape_travels_with_the_tuning_text():
+    """CelebA's default two_streams = "auto": whether a shape runs as one row group or two is timed when the shape is prepared and
+    written into the tuning text ("groups B R n"); a handle that imports the text runs the same form without timing -- the bench
+    line, the rocprofv3 trace and the PMC passes of tools/collect_profiles.sh (where counters serialise the kernels, so that two
+    groups could never win a timing) then launch the same kernels.  A record for the other form is honoured as well."""
+    g1, p = make_gan("celeba", rec_rr=10, rec_iters=2)
+    g1.prepare(104)
+    n1 = g1.row_groups(104)
+    text = g1.export_tuning()
+    assert ("groups 104 10 %d" % n1) in text.splitlines()
+    other = 2 if n1 == 1 else 1
+    forced = "\n".join(("groups 104 10 %d" % other) if l.startswith("groups 104 10 ") else l for l in text.splitlines()) + "\n"
+    assert tuning_text_id(forced) != tuning_text_id(text)
+    g2, _ = make_gan("celeba", rec_rr=10, rec_iters=2)
+    assert g2.import_tuning(forced) > 0
+    assert g2.row_groups(104) == other
+    g2.prepare(104)                                            # nothing is timed again: the installed choice stands
+    assert g2.row_groups(104) == other and g2.tuning_id() == tuning_text_id(forced)
+
+
 @pytest.mark.parametrize("arch,B,R,L", [("mnist", 24, 5, 6), ("mnist", 50, 10, 4), ("celeba", 6, 10, 3)])
 def test_replayed_loop_graph_reproduces_the_enqueued_launches(arch, B, R, L):
     """(Opt-in.)  Call shapes of at most graph_max_rows latent rows replay a captured graph of the L-step loop (images staged into the

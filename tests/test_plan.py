@@ -438,7 +438,7 @@ def test_tapered_lists_end_on_small_jobs_and_still_cover_everything(lib):
 
 
 def test_committed_tuning_files_describe_lists_this_planner_builds(lib):
-    """profiles/r05_tuning_{mnist,celeba}.txt are what bench.py installs by default (dg_import_tuning) so that its launches are the
+    """profiles/<round>_tuning_{mnist,celeba}.txt (bench.TUNING_FILE) are what bench.py installs by default (dg_import_tuning) so that its launches are the
     ones the committed rocprofv3 / PMC evidence was collected on.  The engine refuses a record whose job count this build's
     planner does not reproduce (bench.py then times afresh and `roofline.traffic` goes null): a change to dg_plan.cpp that
     orphans the committed files must show up here, on the CPU."""
@@ -452,8 +452,9 @@ def test_committed_tuning_files_describe_lists_this_planner_builds(lib):
     }
     slots = {0: 2, 1: 3, 2: 5}                       # dg_handle::job_slots_per_cu
     checked = 0
-    for wl, table in layers.items():
-        path = os.path.join(root, "profiles", "r05_tuning_%s.txt" % wl)
+    import bench
+    for wl, table in [(w, t) for w, t in layers.items() for _ in (0,)]:
+        path = os.path.join(root, "profiles", bench.TUNING_FILE % wl)      # the file bench.py installs (this round's)
         if not os.path.exists(path):
             continue
         lines = open(path).read().splitlines()
