@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libdefensegan_hip.so")
 # the same sources with -DDG_MEASURE: in-kernel phase traces, phase-removal switches and the superseded tail kernels kept as
 # cross-checks (tools/, tests/test_gpu_variants.py).  Never loaded by the product path.
 LIB_MEASURE = os.path.join(LIBDIR, "libdefensegan_hip_measure.so")
-SOURCES = ["dg_engine.cpp", "dg_engine_lists.cpp", "dg_engine_prof.cpp", "dg_engine_opts.cpp", "dg_comm.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_fgemm.hip", "dg_linear.hip", "dg_tail_mnist.hip", "dg_tail_celeba.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
+SOURCES = ["dg_engine.cpp", "dg_engine_lists.cpp", "dg_engine_prof.cpp", "dg_engine_opts.cpp", "dg_comm.cpp", "dg_plan.cpp", "dg_gemm.hip", "dg_fgemm.hip", "dg_linear.hip", "dg_turn.hip", "dg_tail_mnist.hip", "dg_tail_celeba.hip", "dg_bn.hip", "dg_small.hip", "dg_clf.hip"]
 HEADERS = ["dg_engine.h", "dg_kernels.h", "dg_tail_common.h", "dg_device.h", "dg_plan.h", "dg_types.h", os.path.join("..", "..", "include", "defensegan_hip.h")]
 ARCH = "gfx950"
 

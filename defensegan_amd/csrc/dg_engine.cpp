@@ -107,6 +107,9 @@ int build_plans(dg_handle* h) {
     return DG_OK;
 }
 
+// arrival counters of the fused latent turn (dg_turn.hip): one block per concurrent row group, then the error word
+constexpr size_t turn_bar_bytes() { return ((size_t)dg_handle::kMaxGroups * dg_handle::kTurnBarWords + 16) * sizeof(unsigned); }
+
 void free_workspace(dg_handle* h) {
     auto fr = [](float*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
     fr(h->z); fr(h->m); fr(h->part); fr(h->loss); fr(h->y); fr(h->g6); fr(h->loss_part); fr(h->xbuf);
@@ -119,6 +122,7 @@ void free_workspace(dg_handle* h) {
     if (h->bn_part) { (void)hipFree(h->bn_part); h->bn_part = nullptr; }
     fr(h->tail_bn_sums); h->tail_bn_sums_wgs = 0;
     if (h->upd_count) { (void)hipFree(h->upd_count); h->upd_count = nullptr; }
+    if (h->turn_bar) { (void)hipFree(h->turn_bar); h->turn_bar = nullptr; }
     h->cap_rows = 0;
 }
 
@@ -135,6 +139,8 @@ int ensure_workspace(dg_handle* h, int64_t rows) {
         HIP_TRY(hipMalloc(&h->upd_count, n_count * sizeof(unsigned)));
         HIP_TRY(hipMemset(h->upd_count, 0, n_count * sizeof(unsigned)));
     }
+    HIP_TRY(hipMalloc(&h->turn_bar, turn_bar_bytes()));
+    HIP_TRY(hipMemset(h->turn_bar, 0, turn_bar_bytes()));
     HIP_TRY(hipMalloc(&h->loss, cap * sizeof(float)));
     HIP_TRY(hipMalloc(&h->y, cap * h->P * sizeof(float)));
     if (h->graph_max_rows > 0) {
@@ -519,7 +525,8 @@ dg::BnArgs bn_args(dg_handle* h, const ActInfo& a, int n_rows) {
 // images are skipped inside).  With use_bn the whole call is one row group (batch statistics couple all rows).
 // want_loss: the per-row loss is only read after the last step (selection) and by dg_loss_grad; the CelebA tail leaves
 // per-band partial sums, whose reduction is skipped when nobody reads the result.
-int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool want_loss, bool tail_backward, bool prof) {
+int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool want_y, bool want_loss, bool tail_backward, bool prof,
+                bool have_f1 = false) {
     const int n_rows = g.n_rows;
     hipStream_t s = g.s;
     const int64_t r0 = g.row0;
@@ -527,8 +534,10 @@ int run_forward(dg_handle* h, const float* x, const RowGroup& g, int R, bool wan
     // the activation
     auto out_of = [&](int d) { return (h->ai[d].has_bn ? h->ai[d].xhat : h->act[d]) + r0 * h->act_row[d]; };
     const bool frag = frag_on(h) && r0 == 0;
-    int rc = frag ? run_lin_stationary(h, h->F1, h->z, h->act[0], n_rows, s, prof, nullptr, h->actf[0], h->gate[0])
-                  : run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
+    // (have_f1: the previous step's fused latent turn has already left this step's Linear forward in act[0])
+    int rc = have_f1 ? DG_OK
+             : frag  ? run_lin_stationary(h, h->F1, h->z, h->act[0], n_rows, s, prof, nullptr, h->actf[0], h->gate[0])
+                     : run_gemm(h, h->F1, h->z + r0 * h->latent, out_of(0), n_rows, s, prof);
     if (rc) return rc;
     const int nd = (int)h->dec.size();
     // The MNIST tail in its Batchnorm form (this launch runs mnist_tail_pipe3_kernel and the last GEMM is behind a Batchnorm whose sums
@@ -654,7 +663,7 @@ bool update_folds(const dg_handle* h) {
     return h->update_fold && h->upd_count && lin_stationary(h, h->B1) && dg::lin_fold_supported(h->nsplit, h->latent);
 }
 
-int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* uf = nullptr) {
+int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* uf = nullptr, bool without_b1 = false) {
     const int nd = (int)h->dec.size();
     const int64_t r0 = g.row0;
     // Batchnorm backward of activation k: the sums come from the epilogue of the GEMM that wrote dy (EPI_MASK_STATS) or from a pass
@@ -675,8 +684,51 @@ int run_backward(dg_handle* h, const RowGroup& g, bool prof, const UpdateFold* u
         if (rc) return rc;
     }
     if (h->ai[0].has_bn) bn_backward(0);
+    if (without_b1) return DG_OK;                    // the fused latent turn follows (run_latent_turn)
     if (uf) return run_lin_stationary(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof, uf);
     return run_gemm(h, h->B1, h->act[0] + r0 * h->act_row[0], h->part + r0 * h->nsplit * h->latent, g.n_rows, g.s, prof);
+}
+
+// The latent turn as one launch (dg_turn.hip)?  Both Linear layers on their weight-stationary shapes, the Linear output feeding
+// the first deconv directly (no Batchnorm pass, no fragment-order copy), the update not already folded into the backward.
+bool turn_fuses(const dg_handle* h) {
+    return h->turn_fused && h->turn_bar && lin_stationary(h, h->B1) && lin_stationary(h, h->F1) && h->F1.mode == dg::EPI_BIAS_RELU &&
+           dg::turn_fused_supported(h->nsplit, h->latent, h->lin_out) && !h->ai[0].has_bn && !frag_on(h) && !update_folds(h) &&
+           2 * h->cu_count / h->nsplit >= 1;
+}
+
+// Row group `gi` of `ngroups` concurrent ones: da1 in act[0] -> partials -> z, m -> act[0] = next step's relu(z W^T + b).
+int run_latent_turn(dg_handle* h, const RowGroup& g, int gi, int ngroups, float lr, float momentum, bool prof) {
+    const int64_t r0 = g.row0;
+    dg::TurnArgs a;
+    a.dA = h->act[0] + r0 * h->act_row[0];
+    a.Wb = h->lin_pack_bwd;
+    a.part = h->part + r0 * h->nsplit * h->latent;
+    a.z = h->z + r0 * h->latent;
+    a.m = h->m + r0 * h->latent;
+    a.Wf = h->lin_pack_fwd;
+    a.bias = h->F1.bias;
+    a.H = h->act[0] + r0 * h->act_row[0];
+    a.bar = h->turn_bar + (size_t)gi * dg_handle::kTurnBarWords;
+    a.err = h->turn_bar + (size_t)dg_handle::kMaxGroups * dg_handle::kTurnBarWords;
+    a.lr = lr; a.momentum = momentum;
+    a.features = h->lin_out;
+    a.n_rows = g.n_rows;
+    a.nsplit = h->nsplit;
+    // every workgroup of every turn launch that may be in flight at once must be resident: two fit a CU
+    const int n_blocks = (g.n_rows + 31) / 32;
+    int want = h->lin_groups_bwd > 0 ? h->lin_groups_bwd : std::max(1, h->cu_count / h->nsplit);
+    want = std::min(want, std::max(1, 2 * h->cu_count / std::max(1, ngroups) / h->nsplit));
+    want = std::min(want, dg_handle::kTurnBarWords / 2);
+    a.groups = std::min(n_blocks, want);
+#ifdef DG_MEASURE
+    a.trace = (h->d_job_trace && h->job_trace_op == "TURN" && a.nsplit * a.groups * 2 <= kJobTraceCap) ? h->d_job_trace : nullptr;
+#endif
+    {
+        ProfScope ps(h, g.s, prof, "TURN@latent_turn_kernel", 2.0 * (double)(h->B1.bplan.macs_per_row + h->F1.bplan.macs_per_row) * g.n_rows);
+        dg::launch_latent_turn(a, g.s);
+    }
+    return launch_check("the fused latent turn");
 }
 
 // (Re)builds every layer plan and re-attaches the weight pointers (dg_create, tuning options).
@@ -706,6 +758,7 @@ int rebuild_plans(dg_handle* h) {
 int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float momentum, const RowGroup* grp, int ngroups) {
     const int steps = L > 1 ? L : 1;
     const int decay_iter = L > 0 ? (int)std::ceil(0.8 * (double)L) : 1;
+    const bool fused_turn = turn_fuses(h);
     for (int k = 0; k < steps; ++k) {
         const bool last = (k == steps - 1);
         const bool prof = h->prof_stride > 0 && (k % h->prof_stride) == 0;
@@ -715,10 +768,18 @@ int enqueue_steps(dg_handle* h, const float* x, int R, int L, float lr, float mo
         const float lr_k = h->lr_intended ? lr * std::pow(0.1f, (float)(k / decay_iter)) : lr;
         for (int gi = 0; gi < ngroups; ++gi) {
             const RowGroup& g = grp[gi];
-            int rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof);
+            const bool turn = fused_turn && g.n_rows <= dg::kTurnMaxRows;
+            int rc = run_forward(h, x, g, R, /*want_y=*/last, /*want_loss=*/last, /*tail_backward=*/!last, prof, /*have_f1=*/turn && k > 0);
             if (rc) return rc;
             if (last) continue;
             const int64_t r0 = g.row0;
+            if (turn) {
+                rc = run_backward(h, g, prof, nullptr, /*without_b1=*/true);
+                if (rc) return rc;
+                rc = run_latent_turn(h, g, gi, ngroups, lr_k, momentum, prof);
+                if (rc) return rc;
+                continue;
+            }
             if (update_folds(h)) {
                 // row groups are whole images, not whole 32-row blocks: group gi's counters start at r0 / 32 + gi (disjoint)
                 const UpdateFold uf = {h->z + r0 * h->latent, h->m + r0 * h->latent, h->upd_count + r0 / 32 + gi, lr_k, momentum};
@@ -777,6 +838,7 @@ int time_group_forms(dg_handle* h, int B, int R, hipStream_t s, int* best) {
         for (int f = 0; f < 2; ++f) {
             if (hipMemsetAsync(h->z, 0, zbytes, s) != hipSuccess || hipMemsetAsync(h->m, 0, zbytes, s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
             if (update_folds(h) && hipMemsetAsync(h->upd_count, 0, (size_t)(n_rows / 32 + 16) * sizeof(unsigned), s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
+            if (turn_fuses(h) && hipMemsetAsync(h->turn_bar, 0, turn_bar_bytes(), s) != hipSuccess) return done(fail(DG_E_HIP, "hipMemsetAsync failed"));
             RowGroup grp[dg_handle::kMaxGroups];
             const int ng = split_groups(h, B, R, grp, forms[f]);
             for (int gi = 0; gi < ng; ++gi) {
@@ -958,6 +1020,7 @@ int dg_destroy(dg_handle* h) {
     if (!h) return DG_OK;
     (void)hipSetDevice(h->device);
     prof_collect(h);
+    if (h->turn_err_host) { (void)hipHostFree(h->turn_err_host); h->turn_err_host = nullptr; }
     drop_graphs(h);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     free_workspace(h);
@@ -1159,6 +1222,14 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     // (the arrival counters of the folded update return to zero by themselves; cleared per call all the same, so that a call
     // that died half-way cannot poison the next one)
     if (update_folds(h)) HIP_TRY(hipMemsetAsync(h->upd_count, 0, (size_t)(n_rows / 32 + 16) * sizeof(unsigned), s));
+    // (the fused latent turn's barrier counters are monotonic within a call and start every call at zero)
+    if (turn_fuses(h)) {
+        if (h->turn_err_host && *h->turn_err_host) {
+            *h->turn_err_host = 0;
+            return fail(DG_E_HIP, "a barrier of the fused latent turn (option turn_fused) gave up in an earlier call: its results were wrong");
+        }
+        HIP_TRY(hipMemsetAsync(h->turn_bar, 0, turn_bar_bytes(), s));
+    }
     const int steps = L > 1 ? L : 1;
     // the batch split (by image) into row groups on separate streams (option two_streams)
     RowGroup grp[dg_handle::kMaxGroups];
@@ -1201,6 +1272,11 @@ int dg_reconstruct(dg_handle* h, const float* x, const float* z0, uint64_t seed,
     dg::launch_select(h->loss, h->y, B, R, h->P, out_rec, out_idx, s);
     if (out_loss) HIP_TRY(hipMemcpyAsync(out_loss, h->loss, (size_t)n_rows * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_z) HIP_TRY(hipMemcpyAsync(out_z, h->z, zbytes, hipMemcpyDeviceToDevice, s));
+    if (turn_fuses(h)) {          // the turn kernel's "a barrier gave up" word travels to the host behind the call; read by the next call
+        if (!h->turn_err_host) HIP_TRY(hipHostMalloc((void**)&h->turn_err_host, sizeof(unsigned), hipHostMallocDefault));
+        HIP_TRY(hipMemcpyAsync(h->turn_err_host, h->turn_bar + (size_t)dg_handle::kMaxGroups * dg_handle::kTurnBarWords, sizeof(unsigned),
+                               hipMemcpyDeviceToHost, s));
+    }
     HIP_TRY(hipGetLastError());
     return DG_OK;
 }

@@ -165,6 +165,12 @@ struct dg_handle {
     int latent_turn = 1;
     int update_fold = 0;           // momentum update folded into the Linear backward launch (dg_linear.hip); needs latent_turn
     unsigned* upd_count = nullptr; // one arrival counter per 32-row block (+ one per row group), zero between launches
+    // The whole latent turn (Linear backward -> update -> next step's Linear forward) as ONE launch (dg_turn.hip): option
+    // "turn_fused"; needs the weight-stationary shapes, no Batchnorm behind the Linear layer, the NHWC path.  Bit-identical.
+    int turn_fused = 0;
+    static constexpr int kTurnBarWords = 1024;    // arrival counters of one concurrent row group ([workgroup row groups][2])
+    unsigned* turn_bar = nullptr;  // [kMaxGroups][kTurnBarWords] + the error word; zeroed at the start of every call
+    unsigned* turn_err_host = nullptr;   // pinned copy of the error word, fetched behind every call
     int lin_groups_fwd = 0, lin_groups_bwd = 0;   // workgroups per column tile / K slice; 0 = pick from the CU count
     int cu_count = 256;
     double job_slack = 0.0;        // job cutting threshold (dg_plan.h build_jobs); 0 = pick by simulated makespan

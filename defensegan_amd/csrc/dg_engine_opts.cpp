@@ -93,6 +93,13 @@ static int set_option(dg_handle* h, const char* key, const char* value) {
         h->update_fold = atoi(value) != 0;
         return DG_OK;
     }
+    if (k == "turn_fused") {             // 1 = Linear backward + update + next Linear forward as one launch (dg_turn.hip)
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->turn_fused = atoi(value) != 0;
+        ++h->list_epoch;                 // captured loops hold the other launch sequence
+        return DG_OK;
+    }
     if (k == "bn_fused") {               // Batchnorm sums from the producing GEMM's epilogue: 2 = forward and backward (default), 1 = forward, 0 = passes
         HIP_TRY(hipSetDevice(h->device));
         HIP_TRY(hipDeviceSynchronize());

@@ -173,6 +173,37 @@ __host__ __device__ inline long long lin_pack_index(int unit, int wave, int kch,
 }
 void launch_lin_stationary(const LinArgs& a, hipStream_t s);
 
+// ---- the latent turn as one launch (dg_turn.hip; engine option turn_fused) ----------------------
+// Linear backward (partials [n][nsplit][128] of dz from dA [n][features], K slices of 256 features) -> ApplyMomentum on z / m
+// [n][128] -> Linear forward + BiasAdd + ReLU into H [n][features] (dA and H may be the same buffer: a workgroup's forward
+// writes come after its row group's backward reads).  Grid nsplit x groups workgroups; `bar` = two arrival counters per row
+// group ([groups][2]), zeroed by the caller at the start of every call; `err` is raised when a barrier poll gives up.
+// Bit-identical to launch_lin_stationary(backward) + launch_momentum_update + launch_lin_stationary(forward).
+struct TurnArgs {
+    const float* dA;
+    const float* Wb;         // lin_pack_index order, [nsplit][4][8]...   (the backward's K slices)
+    float* part;
+    float* z;
+    float* m;
+    const float* Wf;         // lin_pack_index order, [features / 128][4][4]...   (the forward's column tiles)
+    const float* bias;
+    float* H;
+    unsigned* bar;
+    unsigned* err;
+    float lr, momentum;
+    int features;
+    int n_rows;
+    int nsplit;
+    int groups;              // <= ceil(n_rows / 32)
+#ifdef DG_MEASURE
+    long long* trace;        // optional [grid][8] shader-clock stamps: start, backward ready, backward multiplied, past barrier 1,
+                             // updated, past barrier 2, forward ready, end (tools/turn_trace.py)
+#endif
+};
+constexpr int kTurnMaxRows = 1 << 17;        // the update addresses the partials by 32-bit byte offsets: rows x nsplit x 512 B < 4 GB
+bool turn_fused_supported(int nsplit, int latent, int features);
+void launch_latent_turn(const TurnArgs& a, hipStream_t s);
+
 // ---- MNIST tail: Generator.5 (64 -> 1, 28x28) + sigmoid + loss + backward to da3 --------------
 // dataset_models.py:66-69, gan.py:410-414.  One workgroup per latent row.
 struct MnistTailArgs {

@@ -94,14 +94,18 @@ BITWISE = {
               # the momentum update folded into the Linear backward launch (last-arriving K slice), alone / with other group counts /
               # with two row groups on two streams
               {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 5}, {"update_fold": 1, "lin_groups_bwd": 64},
-              {"update_fold": 1, "two_streams": 2, "two_stream_min_rows": 64}],
+              {"update_fold": 1, "two_streams": 2, "two_stream_min_rows": 64},
+              # the whole latent turn as one launch (dg_turn.hip): alone / other group counts / two and three row groups on streams
+              {"turn_fused": 1}, {"turn_fused": 1, "lin_groups_bwd": 5}, {"turn_fused": 1, "lin_groups_bwd": 64},
+              {"turn_fused": 1, "two_streams": 2, "two_stream_min_rows": 64}, {"turn_fused": 1, "two_streams": 3, "two_stream_min_rows": 64}],
     "celeba": [{"jobs.slack": 1e30, "jobs.min_level": 0}, {"jobs.slack": 0.01}, {"jobs.min_level": 1, "jobs.tune": 0},
                {"jobs.prio": 2}, {"jobs.prio": 0}, {"jobs.pair_kernel": 2},
                {"tail_bwd_persist": 0}, {"tail_bwd_persist": 0, "tail_bwd_bands": 2}, {"tail_bwd_persist": 300},
                {"latent_turn": 0}, {"lin_groups_fwd": 7, "lin_groups_bwd": 1}, {"update_fold": 1}, {"update_fold": 1, "lin_groups_bwd": 3},
                # row groups on streams (CelebA's default for calls of >= 1024 rows), 2 and 3 of them, unequal halves
                {"two_streams": 2, "two_stream_min_rows": 64}, {"two_streams": 3, "two_stream_min_rows": 64},
-               {"two_streams": 2, "two_stream_min_rows": 64, "two_stream_split": 60}],
+               {"two_streams": 2, "two_stream_min_rows": 64, "two_stream_split": 60},
+               {"turn_fused": 1}, {"turn_fused": 1, "lin_groups_bwd": 3}, {"turn_fused": 1, "two_streams": 2, "two_stream_min_rows": 64}],
 }
 
 
@@ -209,6 +213,31 @@ def test_folded_update_is_bit_identical_over_many_steps(B, R, L):
     ref = _run(gan, x, z0)
     g2, _ = _make("mnist", R=R, L=L)
     g2.set_option("update_fold", 1)
+    for rep in range(2):
+        got = _run(g2, x, z0)
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (rep, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
+@pytest.mark.parametrize("arch,B,R,L", [("mnist", 256, 10, 60), ("mnist", 121, 10, 40), ("mnist", 3, 1, 25), ("mnist", 50, 10, 30),
+                                        ("celeba", 64, 10, 20), ("celeba", 7, 3, 12)])
+def test_fused_latent_turn_is_bit_identical_over_many_steps(arch, B, R, L):
+    """Option turn_fused (dg_turn.hip): Linear backward, momentum update and the next step's Linear forward as ONE launch, the
+    workgroups of a row group meeting at two barriers of their own.  Every step reads partials and latents other workgroups --
+    on other XCDs -- wrote into the SAME buffers a step earlier (and, for z, a phase earlier), so one stale word would change z
+    for good: after L steps z, the losses and the selection are bit-identical to the three separate launches', twice in a row
+    (the barrier counters restart at zero with every call), at full, ragged and tiny row counts of both architectures."""
+    a = archs.make_arch(arch)
+    gan, p = _make(arch, R=R, L=L)
+    rs = np.random.RandomState(23)
+    x = gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32))
+    x = np.asarray(x.cpu().numpy() if hasattr(x, "cpu") else x, np.float32)
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=24)
+    z0 = synth.make_z(B * R, 128, seed=25)
+    ref = _run(gan, x, z0)
+    assert np.isfinite(ref["loss"]).all()
+    g2, _ = _make(arch, R=R, L=L)
+    g2.set_option("turn_fused", 1)
     for rep in range(2):
         got = _run(g2, x, z0)
         for k in ("rec", "idx", "loss", "z"):

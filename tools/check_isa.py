@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "defensegan_amd", "csrc")
-SOURCES = ["dg_gemm.hip", "dg_fgemm.hip", "dg_linear.hip", "dg_small.hip", "dg_bn.hip", "dg_clf.hip", "dg_tail_mnist.hip", "dg_tail_celeba.hip"]
+SOURCES = ["dg_gemm.hip", "dg_fgemm.hip", "dg_linear.hip", "dg_turn.hip", "dg_small.hip", "dg_bn.hip", "dg_clf.hip", "dg_tail_mnist.hip", "dg_tail_celeba.hip"]
 
 
 def assembly(src, defines=()):
