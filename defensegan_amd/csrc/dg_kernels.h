@@ -196,8 +196,8 @@ struct TurnArgs {
     int nsplit;
     int groups;              // <= ceil(n_rows / 32)
 #ifdef DG_MEASURE
-    long long* trace;        // optional [grid][8] shader-clock stamps: start, backward ready, backward multiplied, past barrier 1,
-                             // updated, past barrier 2, forward ready, end (tools/turn_trace.py)
+    long long* trace;        // optional [grid][8] stamps of the 100 MHz real-time counter: start, backward ready, backward multiplied,
+                             // partials drained, past barrier 1, updated + z drained, past barrier 2, end (tools/turn_trace.py)
 #endif
 };
 constexpr int kTurnMaxRows = 1 << 17;        // the update addresses the partials by 32-bit byte offsets: rows x nsplit x 512 B < 4 GB

@@ -269,16 +269,17 @@ __global__ __launch_bounds__(256, 2) void latent_turn_kernel(TurnArgs g) {
     // every wave's partials are acknowledged; then the workgroup; then the row group
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    group_barrier(bar + 0, (unsigned)g.nsplit, g.err, [] {});
     DG_TURN_STAMP(3);
+    group_barrier(bar + 0, (unsigned)g.nsplit, g.err, [] {});
+    DG_TURN_STAMP(4);
 
     // ================= phase U: ApplyMomentum on this workgroup's share of the group's rows =================
     if (g.nsplit == 16) turn_update<16, 2>(g, tid, unit, grp, n_my);
     else if (g.nsplit == 32) turn_update<32, 1>(g, tid, unit, grp, n_my);
     else turn_update<8, 2>(g, tid, unit, grp, n_my);
-    DG_TURN_STAMP(4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    DG_TURN_STAMP(5);
 
     // ================= phase F: h = relu(z . W^T + b), column tiles 2 * unit and 2 * unit + 1 of the group's blocks =================
     f32x4 wf0[KF][4], wf1[KF][4];
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void latent_turn_kernel(TurnArgs g) {
         bv0 = *reinterpret_cast<const f32x4*>(g.bias + tile0 * 128 + wave * 32 + ec);
         bv1 = *reinterpret_cast<const f32x4*>(g.bias + (tile0 + 1) * 128 + wave * 32 + ec);
     });
-    DG_TURN_STAMP(5);
+    DG_TURN_STAMP(6);
     {
         auto stage = [&](int blk, char* dst) {
             const int row0 = blk << 5;
@@ -322,7 +323,6 @@ __global__ __launch_bounds__(256, 2) void latent_turn_kernel(TurnArgs g) {
         asm volatile("" : "+v"(bv0));
         asm volatile("" : "+v"(bv1));
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        DG_TURN_STAMP(6);
 
         float* const tb = reinterpret_cast<float*>(epi_f + wave * 8192);
         float* const tb1 = tb + 1024;

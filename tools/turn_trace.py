@@ -38,18 +38,18 @@ t0 = t[:, 0].min()
 us = lambda c: c / 100.0          # s_memrealtime: 100 MHz, one time base for all XCDs
 print("latent turn (%s, %d rows): %d workgroups" % (arch, B * R, len(t)))
 print("  start spread %.2f us; kernel span (first start -> last end) %.2f us" % (us(t[:, 0].max() - t0), us(t[:, 7].max() - t0)))
-names = ["start -> backward ready (weights + first block)", "backward multiplies", "last write-out + drain + barrier 1", "update (loads, fmas, stores issued)",
-         "drain + barrier 2 (forward weights arrive)", "z staged", "forward multiplies + write-out"]
+names = ["start -> backward ready (weights + first block)", "backward multiplies", "last write-out + drain of the partials", "barrier 1 (arrive, poll)",
+         "update (loads, fmas, stores) + drain of z", "barrier 2 (forward weights arrive meanwhile)", "z staged + forward multiplies + write-out"]
 for k, nm in enumerate(names):
     d = us(t[:, k + 1] - t[:, k])
     print("  %-52s mean %7.2f us  p10 %7.2f  p90 %7.2f  max %7.2f" % (nm, d.mean(), np.percentile(d, 10), np.percentile(d, 90), d.max()))
-for k, nm in enumerate(["start", "backward ready", "backward multiplied", "past barrier 1", "updated", "past barrier 2", "forward ready", "end"]):
+for k, nm in enumerate(["start", "backward ready", "backward multiplied", "partials drained", "past barrier 1", "z drained", "past barrier 2", "end"]):
     d = us(t[:, k] - t0)
     print("  at %-20s mean %7.2f us  min %7.2f  max %7.2f" % (nm, d.mean(), d.min(), d.max()))
 # within a row group (16 / 32 consecutive workgroups): how far apart do its workgroups start / reach the barriers?
 ns = int(opts.get("nsplit", 32 if arch == "celeba" else 16))
 if len(t) % ns == 0:
     g = t.reshape(-1, ns, 8)
-    for k, nm in [(0, "start"), (2, "backward multiplied"), (4, "updated")]:
+    for k, nm in [(0, "start"), (2, "backward multiplied"), (3, "partials drained"), (5, "z drained")]:
         sp = us(g[:, :, k].max(axis=1) - g[:, :, k].min(axis=1))
         print("  spread inside a row group at %-20s mean %6.2f us  max %6.2f" % (nm, sp.mean(), sp.max()))
