@@ -206,6 +206,14 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      update; needs latent_turn, latent 128, nsplit a multiple of 8.  Bit-identical to the separate kernel and
  *                      1.6 % SLOWER on the MNIST loop (the reducer of a row group becomes the last arriver of every later block of
  *                      the group: profiles/r04_ab_update_fold.txt).  Default 0
+ *   "turn_fused"       1: the whole latent turn -- Linear backward, momentum update and the NEXT step's Linear forward -- is ONE launch
+ *                      (dg_turn.hip): the nsplit workgroups of a row group meet at two barriers of their own (write-through partials
+ *                      and latents, one monotonic arrival counter per barrier, cleared at the start of every call).  Needs
+ *                      latent_turn, latent 128, K slices of 256 features, no Batchnorm, frag_path 0.  Bit-identical to the three
+ *                      launches and AT PARITY with them (MNIST -0.5 ... +0.2 %, -1.5 % beside CelebA's second row group: the seam
+ *                      inside the launch costs what the two kernel boundaries did, profiles/r06_ab_turn_fused.txt).  A barrier poll
+ *                      that does not end within ~0.5 s gives up (the next dg_reconstruct on the handle fails with DG_E_HIP) instead
+ *                      of hanging the device.  Default 0
  *   "graph_max_rows"   > 0: call shapes of at most this many latent rows replay a captured hipGraph of the L-step loop instead of
  *                      enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum); never while
  *                      the caller's stream is itself capturing).  Default 0 = always enqueue: measured no gain at the reference's
