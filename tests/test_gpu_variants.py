@@ -196,6 +196,41 @@ def test_poisoned_pair_counters_cannot_reach_the_next_call(arch, B, R):
             assert np.array_equal(got[k], ref[k]), (rep, k)
 
 
+@pytest.mark.parametrize("opts", [{}, {"update_fold": 1}, {"turn_fused": 1}])
+def test_handoffs_under_uneven_load_are_bit_identical(opts):
+    """Every in-launch hand-off of the loop (K-pair accumulator images of dg_gemm.hip; with the options, the folded update's and the
+    fused latent turn's partials and latents) read back by another workgroup while a SECOND stream streams 256-MB copies through the
+    same L2s and fabric: workgroups then start and finish unevenly and the readers' caches are warm with other lines -- the
+    conditions under which a missing drain or a cached stale line shows.  Six loaded calls of 2560 rows x 12 steps each reproduce
+    the quiet run bit for bit."""
+    import torch
+    a = archs.make_arch("mnist")
+    B, R, L = 256, 10, 12
+    gan, p = _make("mnist", R=R, L=L)
+    for k, v in opts.items():
+        gan.set_option(k, v)
+    rs = np.random.RandomState(31)
+    x = np.asarray(gan.generate((rs.standard_normal((B, 128)) * 0.09).astype(np.float32)))
+    x = synth.adversarial(x, 0.3, a.in_lo, a.in_hi, seed=32)
+    z0 = synth.make_z(B * R, 128, seed=33)
+    quiet, _ = _make("mnist", R=R, L=L)
+    ref = _run(quiet, x, z0)
+    assert np.isfinite(ref["loss"]).all()
+    assert all(np.array_equal(_run(gan, x, z0)[k], ref[k]) for k in ("rec", "idx", "loss", "z"))      # (quiet, with the options)
+    side = torch.cuda.Stream()
+    src = torch.empty(64 << 20, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(120 + 40 * rep):                      # ~0.1 ms each: the copies outlast the 15-ms call
+                dst.copy_(src, non_blocking=True)
+        got = _run(gan, x, z0)
+        assert not side.query() or rep == 0, "the background copies ended before the call: no load"
+        side.synchronize()
+        for k in ("rec", "idx", "loss", "z"):
+            assert np.array_equal(got[k], ref[k]), (opts, rep, k, np.abs(got[k].astype(np.float64) - ref[k]).max())
+
+
 @pytest.mark.parametrize("B,R,L", [(256, 10, 60), (121, 10, 40), (3, 1, 25)])
 def test_folded_update_is_bit_identical_over_many_steps(B, R, L):
     """Option update_fold: the workgroup that delivers the last K slice of a 32-row block of dz applies the momentum update
