@@ -213,7 +213,9 @@ int64_t dg_debug_read(dg_handle* h, const char* what, float* dst, int64_t n);
  *                      launches and AT PARITY with them (MNIST -0.5 ... +0.2 %, -1.5 % beside CelebA's second row group: the seam
  *                      inside the launch costs what the two kernel boundaries did, profiles/r06_ab_turn_fused.txt).  A barrier poll
  *                      that does not end within ~0.5 s gives up (the next dg_reconstruct on the handle fails with DG_E_HIP) instead
- *                      of hanging the device.  Default 0
+ *                      of hanging the device.  Residency is guaranteed for the row groups of ONE call (two workgroups fit a CU, the
+ *                      engine sizes the launches of concurrent row groups for that); do not run more than two handles with this
+ *                      option at once on one device.  Default 0
  *   "graph_max_rows"   > 0: call shapes of at most this many latent rows replay a captured hipGraph of the L-step loop instead of
  *                      enqueuing its launches one by one (built on the first call with a new (B, R, L, lr, momentum); never while
  *                      the caller's stream is itself capturing).  Default 0 = always enqueue: measured no gain at the reference's
