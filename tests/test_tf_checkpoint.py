@@ -1,8 +1,9 @@
 """CPU: the TensorFlow checkpoint (V2 tensor bundle) reader of SURVEY.md 8f-N1.
 
 No checkpoint written by a real TensorFlow is available (the reference ships none, TF cannot be installed), so these
-tests pin the reader against (a) bytes assembled by hand from the published format description and (b) files produced by
-the module's own writer -- "parity unpinned", as the module header says."""
+tests pin the reader against (a) bytes assembled by hand from the published format description, (b) files produced by
+the module's own writer and (c) index entries encoded by Google's protobuf runtime from the restated schema (an independent
+encoder for the proto layer) -- "parity unpinned", as the module header says."""
 import os
 import struct
 
@@ -32,6 +33,58 @@ def test_varint_and_proto_wire_format():
     buf = b"\x08\x01" + b"\x12" + bytes([len(shape)]) + shape + b"\x20\x10" + b"\x28\x64" + b"\x35" + struct.pack("<I", 0xDEADBEEF)
     e = T._parse_entry("v", buf)
     assert (e.dtype, e.shape, e.shard, e.offset, e.size, e.crc, e.sliced) == (1, (5, 5), 0, 16, 100, 0xDEADBEEF, False)
+
+
+def test_entries_encoded_by_the_protobuf_runtime():
+    """BundleEntryProto / TensorShapeProto bytes produced by Google's protobuf runtime (not by this repository's writer) from the
+    published schema (tensorflow/core/protobuf/tensor_bundle.proto, tensor_shape.proto: field numbers restated below) are read by
+    the hand-written parser: large dims and offsets (multi-byte varints), a named dim, an unknown field a newer writer might add,
+    a sliced entry.  An independent ENCODER for the proto layer; the schema itself stays a restatement."""
+    pb = pytest.importorskip("google.protobuf")
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="dg_tensor_bundle_restated.proto", package="dgt", syntax="proto3")
+    shape = fd.message_type.add(name="TensorShapeProto")
+    dim = shape.nested_type.add(name="Dim")
+    dim.field.add(name="size", number=1, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    dim.field.add(name="name", number=2, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)
+    shape.field.add(name="dim", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".dgt.TensorShapeProto.Dim")
+    shape.field.add(name="unknown_rank", number=3, type=F.TYPE_BOOL, label=F.LABEL_OPTIONAL)
+    sl = fd.message_type.add(name="TensorSliceProto")
+    ext = sl.nested_type.add(name="Extent")
+    ext.field.add(name="start", number=1, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ext.field.add(name="length", number=2, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    sl.field.add(name="extent", number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".dgt.TensorSliceProto.Extent")
+    ent = fd.message_type.add(name="BundleEntryProto")
+    ent.field.add(name="dtype", number=1, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)            # enum DataType on the wire: a varint
+    ent.field.add(name="shape", number=2, type=F.TYPE_MESSAGE, label=F.LABEL_OPTIONAL, type_name=".dgt.TensorShapeProto")
+    ent.field.add(name="shard_id", number=3, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="offset", number=4, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="size", number=5, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="crc32c", number=6, type=F.TYPE_FIXED32, label=F.LABEL_OPTIONAL)
+    ent.field.add(name="slices", number=7, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name=".dgt.TensorSliceProto")
+    ent.field.add(name="from_the_future", number=15, type=F.TYPE_STRING, label=F.LABEL_OPTIONAL)  # (not in the schema: must be skipped)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    desc = pool.FindMessageTypeByName("dgt.BundleEntryProto")
+    Entry = message_factory.GetMessageClass(desc) if hasattr(message_factory, "GetMessageClass") else message_factory.MessageFactory(pool).GetPrototype(desc)
+
+    m = Entry(dtype=1, shard_id=0, offset=(1 << 33) + 12345, size=5 * 5 * 64 * 128 * 4, crc32c=0xFEEDC0DE, from_the_future="x" * 200)
+    for d in (5, 5, 64, 128):
+        m.shape.dim.add(size=d)
+    m.shape.dim[3].name = "filters_out"
+    e = T._parse_entry("Generator.2.Filters", m.SerializeToString())
+    assert (e.dtype, e.shape, e.shard, e.offset, e.size, e.crc, e.sliced) == (1, (5, 5, 64, 128), 0, (1 << 33) + 12345, 819200, 0xFEEDC0DE, False)
+
+    m0 = Entry(dtype=1, size=4, crc32c=1)                      # a scalar: no dims, defaults (shard 0, offset 0) left off the wire
+    e0 = T._parse_entry("s", m0.SerializeToString())
+    assert (e0.shape, e0.shard, e0.offset, e0.size) == ((), 0, 0, 4)
+
+    ms = Entry(dtype=1, shard_id=2, offset=7, size=64, crc32c=3)
+    ms.shape.dim.add(size=4096)
+    ms.slices.add().extent.add(start=0, length=16)
+    es = T._parse_entry("partitioned", ms.SerializeToString())
+    assert es.sliced and es.shard == 2 and es.shape == (4096,)
 
 
 def test_hand_assembled_block_with_prefix_compression():
