@@ -2,22 +2,25 @@
 // update -> Linear forward + BiasAdd + ReLU of the NEXT step.  Reference call sites: tflib/ops/linear.py:129-142 inside the loop
 // body of models/gan.py:409-437 (ApplyMomentum: gan.py:389-391).  Engine option turn_fused.
 //
-// Why: as three launches (dg_linear.hip, dg_small.hip) the turn costs 62 us per GD iteration at 2560 rows for 34 us of matrix
-// pipe: two kernel boundaries, three ramps, and each Linear launch waits for its stationary weights before its first multiply.
-// Here the 16 x 16 workgroups of the backward launch stay: workgroup (K slice s, row group g) multiplies its slice of the
-// group's 32-row blocks exactly as lin_stationary_kernel<8, EPI_STORE> does, the 16 workgroups of a ROW GROUP then meet at a
+// Why it was built: as three launches (dg_linear.hip, dg_small.hip) the turn costs 62 us per GD iteration at 2560 rows for 34 us
+// of matrix pipe: two kernel boundaries, three ramps, and each Linear launch waits for its stationary weights before its first
+// multiply.  Here the 16 x 16 workgroups of the backward launch stay: workgroup (K slice s, row group g) multiplies its slice of
+// the group's 32-row blocks exactly as lin_stationary_kernel<8, EPI_STORE> does, the 16 workgroups of a ROW GROUP then meet at a
 // barrier of their own (no grid-wide barrier: row groups never exchange data), each updates 1/16 of the group's rows
 // (momentum_update_kernel's arithmetic: slices added from zero in slice order, the same two fmas), they meet again, and
 // workgroup (s, g) computes the forward column tiles 2s and 2s + 1 of the group's blocks -- TWO accumulators per wave over ONE
 // staged image of z (the forward's weights arrive while the workgroup waits at the second barrier).
+// What it measured (profiles/r06_ab_turn_fused.txt): 62-69 us -- at parity with the three launches.  The seam inside the launch
+// (drain, arrive, poll, sc1 loads, drain, arrive, poll, sc1 DMA) is 17 us of serialized round trips; OFF by default.
 //
 // Hand-off (programming guide, section 6 guideline 16, {sc1 stores, sc1 loads} form): partials and z leave with write-through
 // (sc1) 16-byte stores, every wave drains (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane adds one to the barrier's monotonic
 // arrival counter (relaxed, agent scope) and polls it with relaxed agent-scope (sc1) loads + s_sleep until its episode is
-// complete, workgroup barrier, then the readers use sc1 loads (partials) / sc1 LDS-DMA (z).  Residency: 80 KB of LDS and 256 registers per lane admit TWO of these workgroups per CU; the engine keeps the workgroups of
-// all turn launches that may be in flight at once (concurrent row groups) within 2 x CUs, and a workgroup only waits for the
-// others of its row group; kernels of other streams finish without this one.  A poll that does not end within
-// ~0.5 s gives up and raises TurnArgs::err (the engine reports it) instead of hanging the device.
+// complete, workgroup barrier, then the readers use sc1 loads (partials) / sc1 LDS-DMA (z).
+// Residency: 80 KB of LDS and at most 256 registers per lane admit TWO of these workgroups per CU; the engine keeps the
+// workgroups of all turn launches that may be in flight at once (concurrent row groups of one call) within 2 x CUs, and a
+// workgroup only waits for the others of its row group; kernels of other streams finish without this one.  A poll that does not
+// end within ~0.5 s gives up and raises TurnArgs::err (the engine fails the handle's next call) instead of hanging the device.
 //
 // Arithmetic: every element of the partials, of z / m and of the activations is produced by the same k-ordered fp32 fma chain
 // and the same expressions as by the three separate kernels: BIT-IDENTICAL (tests/test_gpu_variants.py).
