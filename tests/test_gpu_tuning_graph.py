@@ -98,13 +98,15 @@ def test_the_row_group_choice_of_a_call_shape_travels_with_the_tuning_text():
     assert g2.row_groups(104) == other and g2.tuning_id() == tuning_text_id(forced)
 
 
-@pytest.mark.parametrize("arch,B,R,L", [("mnist", 24, 5, 6), ("mnist", 50, 10, 4), ("celeba", 6, 10, 3)])
-def test_replayed_loop_graph_reproduces_the_enqueued_launches(arch, B, R, L):
+@pytest.mark.parametrize("arch,B,R,L,turn", [("mnist", 24, 5, 6, 0), ("mnist", 50, 10, 4, 0), ("celeba", 6, 10, 3, 0), ("mnist", 50, 10, 7, 1)])
+def test_replayed_loop_graph_reproduces_the_enqueued_launches(arch, B, R, L, turn):
     """(Opt-in.)  Call shapes of at most graph_max_rows latent rows replay a captured graph of the L-step loop (images staged into the
     engine's own buffer): same kernels, same arguments -> bit-identical to enqueuing them, for new images through the same
     graph, for seeded latents, and after an option change rebuilt the graph."""
     g1, p = make_gan(arch, rec_rr=R, rec_iters=L)
     g1.set_option("graph_max_rows", 1024)                      # opt-in (off by default: include/defensegan_hip.h)
+    if turn:                                                   # the captured loop holds the fused latent turn (dg_turn.hip): its barrier
+        g1.set_option("turn_fused", 1)                         # counters are cleared in front of every replay, outside the graph
     g0, _ = make_gan(arch, rec_rr=R, rec_iters=L)
     for seed in (3, 5):
         x = g1.generate(g1.init_latents(B, seed=seed)).contiguous()
