@@ -53,3 +53,9 @@ if len(t) % ns == 0:
     for k, nm in [(0, "start"), (2, "backward multiplied"), (3, "partials drained"), (5, "z drained")]:
         sp = us(g[:, :, k].max(axis=1) - g[:, :, k].min(axis=1))
         print("  spread inside a row group at %-20s mean %6.2f us  max %6.2f" % (nm, sp.mean(), sp.max()))
+    # who drains slowly?  by K slice (= blockIdx % nsplit) and by XCD (= blockIdx % 8)
+    d = us(g[:, :, 3] - g[:, :, 2])
+    print("  write-out + drain by K slice: " + " ".join("%.1f" % v for v in d.mean(axis=0)))
+    print("  barrier 1 by K slice:         " + " ".join("%.1f" % v for v in us(g[:, :, 4] - g[:, :, 3]).mean(axis=0)))
+    print("  share of row groups whose slowest drain is slice k: " + " ".join("%d" % v for v in np.bincount(d.argmax(axis=1), minlength=ns)))
+    print("  write-out + drain by row group: " + " ".join("%.1f" % v for v in d.max(axis=1)))
