@@ -86,6 +86,7 @@ def traffic_for(workload, layers, B, R, tuning_id=None):
 PROFILE_ROUND = "r06"                  # profiles/<round>_*: the evidence collected on this build (tools/final_validation.sh)
 TRAFFIC_FILE = PROFILE_ROUND + "_pmc_traffic.json"
 TUNING_FILE = PROFILE_ROUND + "_tuning_%s.txt"       # profiles/: the job-list choice of the profiling run, per architecture
+COLL_BACKEND = os.environ.get("DG_BENCH_BACKEND", "nccl")     # "gloo": the shared-GPU test mode of the N > 1 flow (see main)
 
 
 def make_inputs(gan, a, B, rank=0, first_image=0):
@@ -382,7 +383,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        # DG_BENCH_BACKEND=gloo (tests/test_gpu_dist.py only): the N > 1 flow -- rank 0's job lists broadcast, the barriers, the
+        # gathers, the max over ranks -- with the control tensors on the CPU, so that two ranks can share the one GPU of a test box
+        # (RCCL refuses two ranks on one device).  The line then says so and reports n_gpus = 1: it is never a multi-GPU number.
+        if COLL_BACKEND == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if COLL_BACKEND == "gloo" else dev      # where the control tensors of the collectives live
 
     arch, wseed, gain, B, R, L = WORKLOADS[args.workload]
     if args.strong:
@@ -486,20 +494,23 @@ def main():
             if rank == 0:
                 for b in shapes:
                     gan.prepare(b)
-                payload = torch.tensor(list(gan.export_tuning().encode()), dtype=torch.uint8, device=dev)
-                n_bytes = torch.tensor([payload.numel()], dtype=torch.int64, device=dev)
+                payload = torch.tensor(list(gan.export_tuning().encode()), dtype=torch.uint8, device=cdev)
+                n_bytes = torch.tensor([payload.numel()], dtype=torch.int64, device=cdev)
             else:
-                n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
+                n_bytes = torch.zeros(1, dtype=torch.int64, device=cdev)
             dist.broadcast(n_bytes, 0)
             if rank != 0:
-                payload = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
+                payload = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=cdev)
             dist.broadcast(payload, 0)
             if rank != 0:
                 gan.import_tuning(bytes(payload.cpu().tolist()).decode())
 
     # rank 0 times / installs its lists and sends them off FIRST and builds its inputs afterwards; the other ranks build their
     # inputs first and pick the lists up when they are done: rank 0's dg_prepare overlaps their setup instead of following it
-    if rank == 0:
+    # (--strong builds its inputs through the engine -- dg_generate times job lists for the shard's row count -- so there rank 0
+    # builds FIRST and its export carries those lists too; the other ranks install before they build: equal shards then run the
+    # same lists in the setup as well, and the per-rank tuning ids of the line agree)
+    if (rank == 0) != bool(args.strong):
         install_job_lists()
         build_inputs()
     else:
@@ -523,7 +534,7 @@ def main():
     if distributed and not args.strong:
         # the path's one exchange: per-image (selected restart, best loss) gathered over RCCL/xGMI
         best = out["loss"].view(B, R).min(dim=1).values
-        msg = torch.stack([out["idx"].float(), best], dim=1).contiguous()
+        msg = torch.stack([out["idx"].float(), best], dim=1).contiguous().to(cdev)
         gathered = [torch.empty_like(msg) for _ in range(world)]
         dist.all_gather(gathered, msg)
     barrier()
@@ -531,7 +542,7 @@ def main():
     per_rank_ms, rank_tuning = [dt / args.steps * 1e3], [tuning_id]
     if distributed:
         # every rank's own time and job-list id (12 hex digits = 6 bytes), then the MAX over ranks is the reported time
-        mine = torch.tensor([dt] + [float(b) for b in bytes.fromhex(tuning_id)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt] + [float(b) for b in bytes.fromhex(tuning_id)], dtype=torch.float64, device=cdev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank_ms = [float(t[0].item()) / args.steps * 1e3 for t in allr]
@@ -560,7 +571,7 @@ def main():
         if top:
             big_layer_us = [round(top["ms"] / top["launches"] * 1e3, 2)]
             if distributed:
-                mine = torch.tensor([big_layer_us[0]], dtype=torch.float64, device=dev)
+                mine = torch.tensor([big_layer_us[0]], dtype=torch.float64, device=cdev)
                 allr = [torch.empty_like(mine) for _ in range(world)]
                 dist.all_gather(allr, mine)
                 big_layer_us = [round(float(t.item()), 2) for t in allr]
@@ -592,7 +603,7 @@ def main():
                   "x = clip(G(z)+0.3*sign(n))" % (arch, L, R, B, cfgno, " with USE_BN: True" if args.use_bn else "", gain))
         res = {
             "metric": "projected images/sec at L=%d,R=%d (%s)" % (L, R, "MNIST 28x28" if a.arch_id == 0 else "CelebA 64x64"),
-            "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": round(value, 3), "unit": "images/s", "n_gpus": 1 if COLL_BACKEND == "gloo" else world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl, "batch_per_gpu": B, "rec_rr": R, "rec_iters": L, "rec_lr": 10.0,

@@ -96,6 +96,33 @@ def test_bench_runs_its_rccl_path_with_one_rank(extra):
         assert res["roofline"]["sum_kernel_ms_per_step"] <= 1.10 * res["ms_per_step"] + 2.0
 
 
+@pytest.mark.parametrize("extra", [[], ["--strong", "--images", "230", "--batch", "100"]])
+def test_bench_two_rank_flow_on_one_gpu_over_gloo(extra):
+    """The driver's N > 1 command line -- torch.distributed.run starting two ranks of bench.py --gpus 2 -- on the one GPU of a test
+    box: DG_BENCH_BACKEND=gloo moves the control tensors of the collectives to the CPU (RCCL refuses two ranks on one device),
+    everything else is the code an 8-GPU run executes: rank 0 installs / times the job lists and broadcasts them, rank 1 imports
+    them, barrier, the timed steps on two engines, the gather, the max over ranks, ONE line from rank 0.  The line says what it is
+    (n_gpus = 1) and carries both ranks' times and job-list ids."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--rec_iters", "4", "--no-cpu-baseline"] + extra
+    env = dict(os.environ)
+    env.update({"DG_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["value"] > 0                       # two ranks shared one GPU: never reported as two
+    assert len(res["ms_per_step_per_rank"]) == 2 and res["ms_per_step"] == pytest.approx(max(res["ms_per_step_per_rank"]), abs=1e-3)
+    assert len(res["tuning_id_per_rank"]) == 2 and len(set(res["tuning_id_per_rank"])) == 1    # rank 1 runs rank 0's job lists
+    assert res["config"]["parallelism"] == "shard2"
+    if extra:
+        assert res["scaling"] == "strong" and 0.0 <= res["accuracy"] <= 1.0
+
+
 _WORKER2 = r"""
 import json, os, sys
 import numpy as np, torch, torch.distributed as dist
