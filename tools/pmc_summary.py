@@ -19,7 +19,7 @@ def summarize(path):
     dur = collections.defaultdict(dict)
     meta = {}
     for k, d, name, v, du, grid, lds, vg, ag, sg in cur:
-        k = k.replace("(anonymous namespace)::", "").split("(")[0][-40:] + " #%d" % grid      # one layer = one (symbol, grid)
+        k = k.replace("(anonymous namespace)::", "").split("(")[0][-48:] + " #%d" % grid      # one layer = one (symbol, grid)
         acc[k][name] += v
         cnt[k].add(d)
         dur[k][d] = du
